@@ -1,0 +1,123 @@
+/* ivosw.h — C ABI of libivosw_hip.so: the MI355X (gfx950) hot path of IVOS-W.
+ *
+ * The reference (svip-lab/IVOS-W) is pure Python over PyTorch ops and has NO FFI/plugin interface
+ * (SURVEY.md §8b); the boundary it offers is the Python class surface models.agent.{Brain,Agent},
+ * models.assessment.{Encoder,AssessNet}.  Each entry point below therefore cites the reference
+ * *method* whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes.  No torch / HIP types in signatures: a stream is passed as
+ *     void* (it is a hipStream_t; NULL = the null stream).
+ *   - Every pointer is a DEVICE pointer owned by the caller unless a parameter says "host".
+ *     The library never allocates or frees device memory and keeps no per-call state: workspaces are
+ *     sized by the *_ws_bytes queries and handed in by the caller.
+ *   - All calls are asynchronous on `stream`; nothing synchronises the device.
+ *   - Return 0 on success, negative on error; ivosw_last_error() gives a thread-local message.
+ *   - Not thread-safe per workspace; distinct workspaces on distinct streams are independent.
+ */
+#ifndef IVOSW_H
+#define IVOSW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVOSW_OK 0
+#define IVOSW_ERR_ARG (-1)      /* bad argument (null pointer, non-positive size, bad enum)   */
+#define IVOSW_ERR_WS (-2)       /* workspace too small                                         */
+#define IVOSW_ERR_LAUNCH (-3)   /* HIP launch / runtime error                                  */
+
+#define IVOSW_F32 0             /* fp32 operands, fp32 accumulate (parity mode)                */
+#define IVOSW_BF16 1            /* bf16 operands, fp32 accumulate (throughput mode)            */
+
+/* Brain parameter arena: the 10 tensors of Brain.state_dict() concatenated in state_dict order
+ * (models/agent.py:13-31): encoder_fc1.{weight[128,2],bias[128]}, encoder_fc2.{weight[128,128],bias[128]},
+ * lstm_cell.{weight_ih[512,128],weight_hh[512,128]}, decoder_fc1.{weight[128,256],bias[128]},
+ * decoder_fc2.{weight[1,128],bias[1]}.                                                         */
+#define IVOSW_BRAIN_NPARAMS 180993
+
+typedef void* ivosw_stream_t;
+
+const char* ivosw_last_error(void);
+int ivosw_version(void);
+
+/* ------------------------------------------------------------------ agent: Brain (K7) --------- */
+/* Replaces Brain.forward (models/agent.py:33-64): x [N,T,2] fp32 -> q [N,T] fp32.
+ * One shared bias-free LSTM cell runs forward and backward over the T frames from a zero state. */
+size_t ivosw_brain_ws_bytes(int N, int T);
+int ivosw_brain_forward(const float* params, const float* x, int N, int T, float* q,
+                        void* ws, size_t ws_bytes, ivosw_stream_t stream);
+/* Replaces Q.argmax() in Agent.action (models/agent.py:187-188): first maximum per row -> idx[N]. */
+int ivosw_brain_argmax(const float* q, int N, int T, int64_t* idx, ivosw_stream_t stream);
+
+/* ------------------------------------------------------------------ agent: DQN step (K8-K10) -- */
+/* Replaces the arithmetic of Agent.update_agent (models/agent.py:128-155):
+ *   a* = argmax policy(s'); Qn = target(s')[a*]; y1 = gamma*Qn + 0.1*r_step; y2 = 0.1*r_done;
+ *   Qsa = policy(s)[action]; loss = mean((Qsa-y1)^2) + mean((Qsa-y2)^2); grads = dLoss/dpolicy.
+ * state/new_state [B,T,2] fp32, action [B] int64, reward_* [B] fp32.  grads [NPARAMS] is overwritten,
+ * *loss is a device float.  The grads are NOT clamped here so that a data-parallel caller can
+ * all-reduce them first (RCCL) and clamp afterwards.                                             */
+size_t ivosw_dqn_ws_bytes(int B, int T);
+int ivosw_dqn_loss_grad(const float* policy, const float* target,
+                        const float* state, const float* new_state, const int64_t* action,
+                        const float* reward_step, const float* reward_done,
+                        int B, int T, float gamma, float* grads, float* loss,
+                        void* ws, size_t ws_bytes, ivosw_stream_t stream);
+/* Replaces grad.clamp_(-1,1) + optim.Adam.step (models/agent.py:157-160, :101): g = clamp(grad*grad_scale);
+ * g += wd*p; m,v update; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  step = t >= 1.
+ * grad_scale = 1/world_size after a sum all-reduce, 1 otherwise.                                 */
+int ivosw_clamp_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n,
+                     int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     float clamp, float grad_scale, ivosw_stream_t stream);
+/* Replaces target_net.load_state_dict(policy_net.state_dict()) (models/agent.py:163-165).        */
+int ivosw_copy_f32(float* dst, const float* src, size_t n, ivosw_stream_t stream);
+
+/* ------------------------------------------------------------------ replay gather (K11) ------- */
+/* Replaces DataLoader shuffle+collate of memory_pool.csv rows (datasets/agent_dataset.py:71-115,
+ * train_agent.py:177-182) for a device-resident SoA replay buffer: columns [cap,T] fp32 and [cap]
+ * scalars; idx [B] int64 -> state/new_state [B,T,2] and the [B] columns of the minibatch.        */
+int ivosw_replay_gather(const float* old_iou, const float* new_iou, const float* annotated,
+                        const float* next_annotated, const int64_t* action, const float* reward_step,
+                        const float* reward_done, const int64_t* idx, int B, int T,
+                        float* state, float* new_state, int64_t* action_out, float* reward_step_out,
+                        float* reward_done_out, ivosw_stream_t stream);
+
+/* ------------------------------------------------------------------ assessment front end ------ */
+/* Replaces (tp>0.5) + AssessNet.all2yxhw(scale=1.5) (models/assessment.py:165-166,110-161) with no D2H:
+ * tp [B,H,W] fp32 -> yxhw [B,4] fp32 (y,x,h,w).  scratch: B*4 int32.                              */
+int ivosw_mask_bbox(const float* tp, int B, int H, int W, float* yxhw, int32_t* scratch,
+                    ivosw_stream_t stream);
+/* Replaces get_ROI_grid + 2x F.grid_sample + the (f-mean)/std of Encoder.forward
+ * (models/assessment.py:75-108,173-174,47): tf [B,3,H,W], tp [B,H,W] fp32 NCHW, yxhw [B,4] ->
+ * roi [B,256,256,4] NHWC (R,G,B normalised, P raw) in `dtype`.                                    */
+int ivosw_roi_sample(const float* tf, const float* tp, const float* yxhw, int B, int H, int W,
+                     int dtype, void* roi, ivosw_stream_t stream);
+
+/* ------------------------------------------------------------------ assessment network -------- */
+/* Packed weights (BN folded in fp32, K-major repack, stem conv1|conv1_p concatenated along Cin).
+ * `tensors` is a HOST array of 326 DEVICE pointers, one per entry of AssessNet.state_dict() in
+ * state_dict order (models/assessment.py:12-71 + torchvision ResNet-50); fp32
+ * tensors as stored, num_batches_tracked entries are ignored (may be NULL).                       */
+#define IVOSW_ASSESS_NTENSORS 326
+size_t ivosw_assess_packed_bytes(int dtype);
+int ivosw_assess_pack(void* packed, int dtype, const void* const* tensors, int ntensors,
+                      ivosw_stream_t stream);
+/* Replaces AssessNet.forward (models/assessment.py:164-182): tf [B,3,H,W], tp [B,H,W] fp32 ->
+ * scores [B] fp32.  Frames are processed in chunks of `chunk` (<=0: library default) so that
+ * layer-to-layer activations stay in the 256 MiB Infinity Cache.
+ * tap_stage/tap_out (debug, tests): 0 = none; 1 roi[.,256,256,4] 2 stem[.,128,128,64] 3 pool[.,64,64,64]
+ * 4..7 res2..res5 outputs, NHWC in `dtype`; 8 pooled [.,2048] fp32.  Only with B <= chunk.        */
+size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk);
+int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp,
+                         int B, int H, int W, float* scores, void* ws, size_t ws_bytes, int chunk,
+                         int tap_stage, void* tap_out, ivosw_stream_t stream);
+/* Name of the dominant kernel of the last ivosw_assess_forward configuration (for profiling).     */
+const char* ivosw_assess_dominant_kernel(int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVOSW_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of libivosw_hip.so — the only way the host classes reach the arithmetic.
+
+No CPU fallback exists: ``lib()`` raises if the shared library is missing, and ``dptr`` rejects
+non-CUDA tensors, so a product call without the HIP extension fails loudly.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libivosw_hip.so")
+
+F32, BF16 = 0, 1
+BRAIN_NPARAMS = 180993
+ASSESS_NTENSORS = 326
+
+_p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+SIGNATURES = {
+    "ivosw_last_error": (C.c_char_p, []),
+    "ivosw_version": (_i, []),
+    "ivosw_brain_ws_bytes": (_sz, [_i, _i]),
+    "ivosw_brain_forward": (_i, [_p, _p, _i, _i, _p, _p, _sz, _p]),
+    "ivosw_brain_argmax": (_i, [_p, _i, _i, _p, _p]),
+    "ivosw_dqn_ws_bytes": (_sz, [_i, _i]),
+    "ivosw_dqn_loss_grad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
+    "ivosw_clamp_adam": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p]),
+    "ivosw_copy_f32": (_i, [_p, _p, _sz, _p]),
+    "ivosw_replay_gather": (_i, [_p] * 8 + [_i, _i] + [_p] * 5 + [_p]),
+    "ivosw_mask_bbox": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "ivosw_roi_sample": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "ivosw_assess_packed_bytes": (_sz, [_i]),
+    "ivosw_assess_pack": (_i, [_p, _i, C.POINTER(_p), _i, _p]),
+    "ivosw_assess_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ivosw_assess_forward": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _sz, _i, _i, _p, _p]),
+    "ivosw_assess_dominant_kernel": (C.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"ivos_w_amd: {LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). There is no CPU fallback for the hot path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("IVOSW_BRINGUP_PARTIAL") and not hasattr(h, name):
+                continue                    # bring-up only: a partially built library
+            fn = getattr(h, name)           # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"ivosw {what} failed ({rc}): {lib().ivosw_last_error().decode()}")
+
+
+def dptr(t, dtype=None):
+    """Raw device pointer of a contiguous CUDA tensor (raises for CPU tensors: no fallback)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("ivos_w_amd: the hot path runs on the MI355X only — got a non-CUDA tensor "
+                           "(move inputs/modules to the GPU; there is no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Workspace:
+    """Grow-only byte workspace on one device (torch caching allocator owns the memory)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf

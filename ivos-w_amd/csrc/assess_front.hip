@@ -1,0 +1,191 @@
+// Assessment front end: mask -> bounding box (K1/K2) and fused ROI resample + normalise (K3).
+//
+// Reference: AssessNet.forward/all2yxhw/get_ROI_grid (models/assessment.py:164-174,110-161,75-108) and
+// Encoder.forward's (f-mean)/std (:47).  The reference copies the mask to the host and loops in numpy;
+// here a coalesced scan reduces min/max per sample with wavefront reductions + one atomic per block, the
+// float64 box arithmetic runs in a per-sample epilogue thread, and the 256x256x2 sampling grid (and the
+// unused inverse grid) is never materialised: sample coordinates are recomputed from (y,x,h,w) per pixel.
+// Both kernels are HBM-bound streaming/gather work; no LDS staging is needed (each input byte is read once).
+#include <limits.h>
+
+#include "common.h"
+#include "front.h"
+
+namespace ivosw {
+
+__global__ void bbox_init_kernel(int32_t* __restrict__ box, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    box[b * 4 + 0] = INT_MAX;  // ymin
+    box[b * 4 + 1] = -1;       // ymax
+    box[b * 4 + 2] = INT_MAX;  // xmin
+    box[b * 4 + 3] = -1;       // xmax
+}
+
+// grid (S, B): block s scans elements [s*chunk, (s+1)*chunk) of sample b's flat H*W plane.
+__global__ __launch_bounds__(256) void bbox_scan_kernel(const float* __restrict__ tp, int H, int W, int chunk,
+                                                        int vec_ok, int32_t* __restrict__ box) {
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const float* p = tp + (size_t)b * plane;
+    const size_t beg = (size_t)blockIdx.x * chunk;
+    const size_t end = min(plane, beg + (size_t)chunk);
+    int ymin = INT_MAX, ymax = -1, xmin = INT_MAX, xmax = -1;
+    if (vec_ok) {  // plane % 4 == 0, chunk % 4 == 0, base 16-B aligned: 16 B per lane, fully coalesced
+        for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e[j] > 0.5f) {  // tm = (tp > 0.5); mask >= 0.49 on {0,1} is the same set (assessment.py:165,115)
+                    ymin = min(ymin, y); ymax = max(ymax, y);
+                    xmin = min(xmin, x); xmax = max(xmax, x);
+                }
+                if (++x == W) { x = 0; ++y; }
+            }
+        }
+    } else {
+        for (size_t i = beg + threadIdx.x; i < end; i += 256) {
+            if (p[i] > 0.5f) {
+                const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+                ymin = min(ymin, y); ymax = max(ymax, y);
+                xmin = min(xmin, x); xmax = max(xmax, x);
+            }
+        }
+    }
+    ymin = wave_min(ymin); ymax = wave_max(ymax);
+    xmin = wave_min(xmin); xmax = wave_max(xmax);
+    __shared__ int red[4][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave][0] = ymin; red[wave][1] = ymax; red[wave][2] = xmin; red[wave][3] = xmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            ymin = min(ymin, red[w][0]); ymax = max(ymax, red[w][1]);
+            xmin = min(xmin, red[w][2]); xmax = max(xmax, red[w][3]);
+        }
+        if (ymax >= 0) {
+            atomicMin(&box[b * 4 + 0], ymin); atomicMax(&box[b * 4 + 1], ymax);
+            atomicMin(&box[b * 4 + 2], xmin); atomicMax(&box[b * 4 + 3], xmax);
+        }
+    }
+}
+
+// integer box -> (y,x,h,w) fp32 with the reference's mixed int/float64 arithmetic (assessment.py:118-157)
+__global__ void bbox_finalize_kernel(const int32_t* __restrict__ box, int B, int H, int W, float* __restrict__ yxhw) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int y0 = box[b * 4 + 0], y1 = box[b * 4 + 1], x0 = box[b * 4 + 2], x1 = box[b * 4 + 3];
+    if (y1 < 0) { y0 = 0; y1 = H; x0 = 0; x1 = W; }  // empty mask: whole frame, H and W (not H-1, W-1)
+    if (y1 - y0 < 128) { const int half = (int)((128.0 - (double)(y1 - y0)) / 2.0); y0 -= half; y1 += half; }
+    if (x1 - x0 < 128) { const int half = (int)((128.0 - (double)(x1 - x0)) / 2.0); x0 -= half; x1 += half; }
+    const double oh = (double)(y1 - y0 + 1), ow = (double)(x1 - x0 + 1);
+    const double k = (1.5 - 1.0) / 2.0;
+    const double fy0 = fmax(-5.0, (double)y0 - k * oh), fy1 = fmin((double)H + 5.0, (double)y1 + k * oh);
+    const double fx0 = fmax(-5.0, (double)x0 - k * ow), fx1 = fmin((double)W + 5.0, (double)x1 + k * ow);
+    yxhw[b * 4 + 0] = (float)((fy1 + fy0) / 2.0);
+    yxhw[b * 4 + 1] = (float)((fx1 + fx0) / 2.0);
+    yxhw[b * 4 + 2] = (float)(fy1 - fy0 + 1.0);
+    yxhw[b * 4 + 3] = (float)(fx1 - fx0 + 1.0);
+}
+
+void launch_mask_bbox(const float* tp, int B, int H, int W, float* yxhw, int32_t* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(bbox_init_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scratch, B);
+    const size_t plane = (size_t)H * W;
+    int S = (int)max((size_t)1, min((size_t)64, (size_t)2048 / (size_t)B));
+    size_t chunk = (plane + S - 1) / S;
+    chunk = (chunk + 1023) / 1024 * 1024;  // multiple of 4 (and of the 1024-element block stride)
+    S = (int)((plane + chunk - 1) / chunk);
+    const int vec_ok = (plane % 4 == 0) && ((reinterpret_cast<uintptr_t>(tp) & 15) == 0);
+    hipLaunchKernelGGL(bbox_scan_kernel, dim3(S, B), dim3(256), 0, st, tp, H, W, (int)chunk, vec_ok, scratch);
+    hipLaunchKernelGGL(bbox_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scratch, B, H, W, yxhw);
+}
+
+// ---------------------------------------------------------------- ROI sampler
+__device__ __forceinline__ float lin_m1_1(int j, int n) {  // torch.linspace(-1,1,n)[j] in fp32
+    const float step = 2.0f / (float)(n - 1);
+    return (j < n / 2) ? __fadd_rn(-1.0f, __fmul_rn((float)j, step)) : __fsub_rn(1.0f, __fmul_rn((float)(n - 1 - j), step));
+}
+
+// grid (256 rows, B), block 256 (one output pixel per thread): roi[b][i][j][0..3] = (R,G,B normalised, P)
+template <typename T>
+__global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict__ tf, const float* __restrict__ tp,
+                                                         const float* __restrict__ yxhw, int H, int W, RoiNorm nrm,
+                                                         T* __restrict__ roi) {
+    const int b = blockIdx.y, i = blockIdx.x, j = threadIdx.x;
+    const float ry = yxhw[b * 4 + 0], rx = yxhw[b * 4 + 1], rh = yxhw[b * 4 + 2], rw = yxhw[b * 4 + 3];
+    // get_ROI_grid (assessment.py:79-92), fp32, no fma contraction so the sample points match the reference
+    const float ymin = __fsub_rn(ry, rh / 2.0f), ymax = __fadd_rn(ry, rh / 2.0f);
+    const float xmin = __fsub_rn(rx, rw / 2.0f), xmax = __fadd_rn(rx, rw / 2.0f);
+    const float wm = (float)(W - 1), hm = (float)(H - 1);
+    const float t00 = __fsub_rn(xmax, xmin) / wm, t02 = __fsub_rn(__fadd_rn(xmin, xmax), wm) / wm;
+    const float t11 = __fsub_rn(ymax, ymin) / hm, t12 = __fsub_rn(__fadd_rn(ymin, ymax), hm) / hm;
+    // affine_grid + grid_sample(align_corners=True): pixel = ((g + 1) / 2) * (size - 1)
+    const float gx = __fadd_rn(__fmul_rn(lin_m1_1(j, 256), t00), t02);
+    const float gy = __fadd_rn(__fmul_rn(lin_m1_1(i, 256), t11), t12);
+    const float sx = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.0f), 0.5f), wm);
+    const float sy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.0f), 0.5f), hm);
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wx1 = __fsub_rn(sx, x0f), wx0 = __fsub_rn(__fadd_rn(x0f, 1.0f), sx);
+    const float wy1 = __fsub_rn(sy, y0f), wy0 = __fsub_rn(__fadd_rn(y0f, 1.0f), sy);
+    const float w_nw = __fmul_rn(wx0, wy0), w_ne = __fmul_rn(wx1, wy0), w_sw = __fmul_rn(wx0, wy1), w_se = __fmul_rn(wx1, wy1);
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+    const size_t plane = (size_t)H * W;
+    const size_t o_nw = (size_t)y0 * W + x0;
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* src = (c < 3) ? tf + ((size_t)b * 3 + c) * plane : tp + (size_t)b * plane;
+        float acc = 0.f;  // zero padding: out-of-range taps contribute nothing
+        if (vy0 && vx0) acc = __fadd_rn(acc, __fmul_rn(src[o_nw], w_nw));
+        if (vy0 && vx1) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + 1], w_ne));
+        if (vy1 && vx0) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + W], w_sw));
+        if (vy1 && vx1) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + W + 1], w_se));
+        out[c] = (c < 3) ? __fsub_rn(acc, nrm.mean[c]) / nrm.std[c] : acc;  // (f - mean) / std after the zero pad
+    }
+    T* dst = roi + (((size_t)b * 256 + i) * 256 + j) * 4;
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+    } else {
+        ushort4 v;
+        v.x = f32_to_bf16(out[0]); v.y = f32_to_bf16(out[1]); v.z = f32_to_bf16(out[2]); v.w = f32_to_bf16(out[3]);
+        *reinterpret_cast<ushort4*>(dst) = v;
+    }
+}
+
+void launch_roi_sample(const float* tf, const float* tp, const float* yxhw, int B, int H, int W, int dtype,
+                       const RoiNorm& nrm, void* roi, hipStream_t st) {
+    if (dtype == IVOSW_F32)
+        hipLaunchKernelGGL(roi_sample_kernel<float>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, H, W, nrm,
+                           static_cast<float*>(roi));
+    else
+        hipLaunchKernelGGL(roi_sample_kernel<bf16_t>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, H, W, nrm,
+                           static_cast<bf16_t*>(roi));
+}
+
+}  // namespace ivosw
+
+using namespace ivosw;
+
+extern "C" int ivosw_mask_bbox(const float* tp, int B, int H, int W, float* yxhw, int32_t* scratch,
+                               ivosw_stream_t stream) {
+    IVOSW_REQUIRE(tp && yxhw && scratch, "null pointer");
+    IVOSW_REQUIRE(B > 0 && H > 0 && W > 0, "B, H, W must be positive");
+    launch_mask_bbox(tp, B, H, W, yxhw, scratch, as_stream(stream));
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+extern "C" int ivosw_roi_sample(const float* tf, const float* tp, const float* yxhw, int B, int H, int W, int dtype,
+                                void* roi, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(tf && tp && yxhw && roi, "null pointer");
+    IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
+    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
+    RoiNorm nrm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};  // Encoder.mean/std buffers (assessment.py:41-44)
+    launch_roi_sample(tf, tp, yxhw, B, H, W, dtype, nrm, roi, as_stream(stream));
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}

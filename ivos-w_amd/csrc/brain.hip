@@ -1,0 +1,558 @@
+// Brain (bidirectional shared-cell LSTM Q-network) forward, Double-DQN loss and hand-derived backward.
+//
+// Reference arithmetic: Brain.forward (models/agent.py:33-64), Agent.update_agent (:128-155).
+//
+// Layout: the shared cell's input-side gates W_ih*e_t do not depend on the direction, so they are one
+// batched GEMM over all (n,t); only h*W_hh^T is sequential.  The recurrence kernel keeps the whole
+// 512x128 fp32 W_hh in VGPRs (one gate column per thread, 512 threads = the CU's register file) and
+// walks the T steps with h broadcast from LDS: rows (sample x direction) map to workgroups, so a
+// 128-sample minibatch fills all 256 CUs.  fp32 throughout (exact fma chains); MFMA is used for the
+// dense batched contractions only (gemm_f32.h).
+#include "gemm_f32.h"
+
+namespace ivosw {
+
+// offsets (floats) into the parameter / gradient arena, state_dict order
+constexpr int O_W1 = 0, O_B1 = 256, O_W2 = 384, O_B2 = 16768, O_WIH = 16896, O_WHH = 82432, O_W3 = 147968,
+              O_B3 = 180736, O_W4 = 180864, O_B4 = 180992;
+static_assert(O_B4 + 1 == IVOSW_BRAIN_NPARAMS, "arena layout");
+constexpr int HD = 128;
+
+// ---------------------------------------------------------------- small kernels
+// a1[row][j] = relu(W1[j,:].x[row] + b1[j])        (encoder_fc1 + relu, agent.py:49)
+__global__ void enc1_kernel(const float* __restrict__ prm, const float* __restrict__ x, int rows, float* __restrict__ a1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * HD) return;
+    const int row = i >> 7, j = i & 127;
+    const float x0 = x[row * 2], x1 = x[row * 2 + 1];
+    const float v = fmaf(x1, prm[O_W1 + j * 2 + 1], fmaf(x0, prm[O_W1 + j * 2], prm[O_B1 + j]));
+    a1[i] = fmaxf(v, 0.f);
+}
+
+// q[row] = d1[row,:].w4 + b4                       (decoder_fc2, agent.py:61)
+__global__ void dec2_kernel(const float* __restrict__ prm, const float* __restrict__ d1, int rows, float* __restrict__ q) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* r = d1 + (size_t)row * HD;
+    float s = r[lane] * prm[O_W4 + lane] + r[lane + 64] * prm[O_W4 + lane + 64];
+    s = wave_sum(s);
+    if (lane == 0) q[row] = s + prm[O_B4];
+}
+
+// out[n] = sum_m A[m*ld + n]; grid = ceil(N/32), block = 1024 (32 cols x 32 row groups)
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ A, int M, int N, int ld, float* __restrict__ out) {
+    __shared__ float red[32][33];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
+    float s = 0.f;
+    if (n < N)
+        for (int m = rg; m < M; m += 32) s += A[(size_t)m * ld + n];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][c];
+        out[n] = t;
+    }
+}
+
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
+// ---------------------------------------------------------------- forward recurrence
+struct LstmFwd {
+    const float* whh;  // [512,128]
+    const float* gx;   // [N,T,512]  W_ih*e_t
+    float* hs;         // [N,T,256]  (fw | bw) h after consuming frame t
+    float* gates;      // [2,N,T,512] post-activation i,f,g,o   (nullable)
+    float* cs;         // [2,N,T,128]                           (nullable)
+    float* hprev;      // [2,N,T,128] h before consuming frame t (nullable)
+    int N, T;
+    int keep_from;     // samples >= keep_from store gates/cs/hprev
+};
+
+template <int R>
+__global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwd p) {
+    __shared__ __attribute__((aligned(16))) float h_s[R][HD];
+    __shared__ float c_s[R][HD];
+    __shared__ float g_s[R][4 * HD];
+    const int tid = threadIdx.x;
+    float w[HD];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(p.whh + (size_t)tid * HD);
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+            const float4 v = wp[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    }
+    if (tid < HD) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { h_s[r][tid] = 0.f; c_s[r][tid] = 0.f; }
+    }
+    __syncthreads();
+    // g gate: tanh(x) = 2*sigmoid(2x) - 1, so all four gate types share one branch-free exp path
+    const float gk = ((tid >> 7) == 2) ? 2.0f : 1.0f;
+    const int Nk = p.N - p.keep_from;  // kept buffers are indexed by (sample - keep_from)
+    const int row0 = blockIdx.x * R;
+    for (int s = 0; s < p.T; ++s) {
+        // rows one at a time in a rolled loop: W_hh owns the register file, per-row state lives in LDS
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (row >= 2 * p.N) break;
+            const int d = row / p.N, n = row - d * p.N;
+            const int t = d ? p.T - 1 - s : s;
+            float a = p.gx[((size_t)n * p.T + t) * 512 + tid];
+            // h == 0 at s == 0, so the first step needs no special case (fma(0,w,a) == a)
+#pragma unroll
+            for (int kc = 0; kc < HD / 4; ++kc) {
+                const float4 h4 = *reinterpret_cast<const float4*>(&h_s[r][kc * 4]);
+                a = fmaf(h4.x, w[4 * kc], a);
+                a = fmaf(h4.y, w[4 * kc + 1], a);
+                a = fmaf(h4.z, w[4 * kc + 2], a);
+                a = fmaf(h4.w, w[4 * kc + 3], a);
+            }
+            const float sg = 1.0f / (1.0f + expf(-gk * a));
+            const float act = fmaf(sg, gk, 1.0f - gk);
+            g_s[r][tid] = act;
+            if (p.gates && n >= p.keep_from)
+                p.gates[(((size_t)d * Nk + (n - p.keep_from)) * p.T + t) * 512 + tid] = act;
+        }
+        __syncthreads();
+        if (tid < HD) {
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                const int row = row0 + r;
+                if (row >= 2 * p.N) break;
+                const int d = row / p.N, n = row - d * p.N;
+                const int t = d ? p.T - 1 - s : s;
+                const float gi = g_s[r][tid], gf = g_s[r][HD + tid], gg = g_s[r][2 * HD + tid], go = g_s[r][3 * HD + tid];
+                const bool keep = p.gates && n >= p.keep_from;
+                const size_t sidx = (((size_t)d * Nk + (n - p.keep_from)) * p.T + t) * HD + tid;
+                if (keep) p.hprev[sidx] = h_s[r][tid];
+                const float c = fmaf(gf, c_s[r][tid], gi * gg);
+                const float h = go * tanhf_(c);
+                c_s[r][tid] = c;
+                h_s[r][tid] = h;
+                p.hs[((size_t)n * p.T + t) * 256 + d * HD + tid] = h;
+                if (keep) p.cs[sidx] = c;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- backward recurrence (BPTT)
+struct LstmBwd {
+    const float* whh;    // [512,128]
+    const float* gates;  // [2,Nk,T,512]   (Nk kept samples, sample index relative to keep_from)
+    const float* cs;     // [2,Nk,T,128]
+    const float* dhc;    // [Nk,256] dL/d(h_fw|h_bw) at frame action[n] (the only frame with loss)
+    const int64_t* action;  // [Nk]
+    float* dG;           // [2,Nk,T,512] dL/d(gate pre-activation)
+    int N, T;            // N = Nk
+};
+
+template <int R>
+__global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwd p) {
+    __shared__ __attribute__((aligned(16))) float dp_s[R][4 * HD];
+    __shared__ float part_s[R][4][HD];
+    const int tid = threadIdx.x, k = tid & 127, part = tid >> 7;
+    float w[HD];
+#pragma unroll
+    for (int j = 0; j < HD; ++j) w[j] = p.whh[(size_t)(part * HD + j) * HD + k];
+    int dn[R], nn[R], s0[R];
+    bool ok[R];
+    int smax = -1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = blockIdx.x * R + r;
+        ok[r] = row < 2 * p.N;
+        dn[r] = ok[r] ? row / p.N : 0;
+        nn[r] = ok[r] ? row % p.N : 0;
+        int a = ok[r] ? (int)p.action[nn[r]] : 0;
+        a = min(max(a, 0), p.T - 1);
+        s0[r] = ok[r] ? (dn[r] ? p.T - 1 - a : a) : -1;  // step at which frame `action` is consumed
+        smax = max(smax, s0[r]);
+    }
+    // steps after the loss frame carry no gradient
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!ok[r]) continue;
+        for (int s = s0[r] + 1; s < p.T; ++s) {
+            const int t = dn[r] ? p.T - 1 - s : s;
+            p.dG[(((size_t)dn[r] * p.N + nn[r]) * p.T + t) * 512 + tid] = 0.f;
+        }
+    }
+    float dh_rec[R], dc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { dh_rec[r] = 0.f; dc[r] = 0.f; }
+
+    for (int s = smax; s >= 0; --s) {
+        if (tid < HD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float di = 0.f, df = 0.f, dg = 0.f, dO = 0.f;
+                if (ok[r] && s <= s0[r]) {
+                    const int t = dn[r] ? p.T - 1 - s : s;
+                    const size_t rt = ((size_t)dn[r] * p.N + nn[r]) * p.T + t;
+                    const float* gp = p.gates + rt * 512;
+                    const float gi = gp[tid], gf = gp[HD + tid], gg = gp[2 * HD + tid], go = gp[3 * HD + tid];
+                    const float cc = p.cs[rt * HD + tid];
+                    const int tprev = dn[r] ? t + 1 : t - 1;
+                    const float cprev = (s > 0) ? p.cs[(((size_t)dn[r] * p.N + nn[r]) * p.T + tprev) * HD + tid] : 0.f;
+                    float dh = dh_rec[r];
+                    if (s == s0[r]) dh += p.dhc[(size_t)nn[r] * 256 + dn[r] * HD + tid];
+                    const float tc = tanhf_(cc);
+                    dc[r] = fmaf(dh * go, 1.f - tc * tc, dc[r]);
+                    di = dc[r] * gg * gi * (1.f - gi);
+                    df = dc[r] * cprev * gf * (1.f - gf);
+                    dg = dc[r] * gi * (1.f - gg * gg);
+                    dO = dh * tc * go * (1.f - go);
+                    dc[r] *= gf;
+                    float* o = p.dG + rt * 512;
+                    o[tid] = di; o[HD + tid] = df; o[2 * HD + tid] = dg; o[3 * HD + tid] = dO;
+                }
+                dp_s[r][tid] = di; dp_s[r][HD + tid] = df; dp_s[r][2 * HD + tid] = dg; dp_s[r][3 * HD + tid] = dO;
+            }
+        }
+        __syncthreads();
+        if (s > 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int jc = 0; jc < HD / 4; ++jc) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(&dp_s[r][part * HD + jc * 4]);
+                    a = fmaf(d4.x, w[4 * jc], a);
+                    a = fmaf(d4.y, w[4 * jc + 1], a);
+                    a = fmaf(d4.z, w[4 * jc + 2], a);
+                    a = fmaf(d4.w, w[4 * jc + 3], a);
+                    if ((jc & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+                part_s[r][part][k] = a;
+            }
+        }
+        __syncthreads();
+        if (s > 0 && tid < HD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                dh_rec[r] = (part_s[r][0][tid] + part_s[r][1][tid]) + (part_s[r][2][tid] + part_s[r][3][tid]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- forward driver
+struct FwdBufs {
+    float *a1, *e, *gx, *hs, *d1, *q;
+    float *gates, *cs, *hprev;  // nullable; indexed by (sample - keep_from)
+    int keep_from;
+};
+
+static size_t fwd_bufs_floats(int N, int T, int nkeep) {
+    const size_t r = (size_t)N * T;
+    size_t n = r * 128 + r * 128 + r * 512 + r * 256 + r * 128 + r;  // a1,e,gx,hs,d1,q
+    n += (size_t)2 * nkeep * T * (512 + 128 + 128);
+    return n + 64 * 16;  // alignment slack
+}
+
+static FwdBufs carve_fwd(Arena& ar, int N, int T, int keep_from) {
+    const size_t r = (size_t)N * T;
+    FwdBufs b{};
+    b.a1 = ar.take<float>(r * 128);
+    b.e = ar.take<float>(r * 128);
+    b.gx = ar.take<float>(r * 512);
+    b.hs = ar.take<float>(r * 256);
+    b.d1 = ar.take<float>(r * 128);
+    b.q = ar.take<float>(r);
+    b.keep_from = keep_from;
+    const int nkeep = (keep_from >= 0 && keep_from < N) ? N - keep_from : 0;
+    if (nkeep > 0) {
+        b.gates = ar.take<float>((size_t)2 * nkeep * T * 512);
+        b.cs = ar.take<float>((size_t)2 * nkeep * T * 128);
+        b.hprev = ar.take<float>((size_t)2 * nkeep * T * 128);
+    }
+    return b;
+}
+
+static int rows_per_wg(int rows) {
+    // one workgroup per CU holds W_hh in registers; more rows than CUs -> several rows share a WG
+    if (rows <= 256) return 1;
+    if (rows <= 512) return 2;
+    return 4;
+}
+
+static void brain_forward_internal(const float* prm, const float* x, int N, int T, const FwdBufs& b, hipStream_t st) {
+    const int rows = N * T;
+    hipLaunchKernelGGL(enc1_kernel, dim3((rows * HD + 255) / 256), dim3(256), 0, st, prm, x, rows, b.a1);
+    GemmF32 g{};
+    // e = a1 * W2^T + b2
+    g.A = b.a1; g.sam = 128; g.sak = 1; g.B = prm + O_W2; g.sbk = 1; g.sbn = 128; g.C = b.e; g.ldc = 128;
+    g.M = rows; g.N = 128; g.K = 128; g.bias = prm + O_B2; g.splitk = 1;
+    launch_gemm_f32(g, st);
+    // gx = e * Wih^T
+    g = GemmF32{};
+    g.A = b.e; g.sam = 128; g.sak = 1; g.B = prm + O_WIH; g.sbk = 1; g.sbn = 128; g.C = b.gx; g.ldc = 512;
+    g.M = rows; g.N = 512; g.K = 128; g.splitk = 1;
+    launch_gemm_f32(g, st);
+    LstmFwd lf{};
+    lf.whh = prm + O_WHH; lf.gx = b.gx; lf.hs = b.hs; lf.N = N; lf.T = T;
+    lf.keep_from = b.gates ? b.keep_from : N;
+    lf.gates = b.gates; lf.cs = b.cs; lf.hprev = b.hprev;
+    const int R = rows_per_wg(2 * N);
+    const int nwg = (2 * N + R - 1) / R;
+    if (R == 1) hipLaunchKernelGGL(lstm_fwd_kernel<1>, dim3(nwg), dim3(512), 0, st, lf);
+    else if (R == 2) hipLaunchKernelGGL(lstm_fwd_kernel<2>, dim3(nwg), dim3(512), 0, st, lf);
+    else hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3(nwg), dim3(512), 0, st, lf);
+    // d1 = relu(relu(hcat) * W3^T + b3)
+    g = GemmF32{};
+    g.A = b.hs; g.sam = 256; g.sak = 1; g.relu_a = 1; g.B = prm + O_W3; g.sbk = 1; g.sbn = 256; g.C = b.d1; g.ldc = 128;
+    g.M = rows; g.N = 128; g.K = 256; g.bias = prm + O_B3; g.relu = 1; g.splitk = 1;
+    launch_gemm_f32(g, st);
+    hipLaunchKernelGGL(dec2_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, prm, b.d1, rows, b.q);
+}
+
+// ---------------------------------------------------------------- DQN head: targets, loss, dQ
+// one block; q_next_pol/q_next_tgt/q_state are [B,T]
+__global__ __launch_bounds__(256) void dqn_head_kernel(const float* __restrict__ q_np, const float* __restrict__ q_nt,
+                                                       const float* __restrict__ q_s, const int64_t* __restrict__ action,
+                                                       const float* __restrict__ r_step, const float* __restrict__ r_done,
+                                                       int B, int T, float gamma, float* __restrict__ dq,
+                                                       float* __restrict__ loss, float* __restrict__ db4) {
+    __shared__ float red[2][256];
+    float l = 0.f, sdq = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* qp = q_np + (size_t)b * T;
+        int am = 0;
+        float best = qp[0];
+        for (int t = 1; t < T; ++t) {
+            const float v = qp[t];
+            if (v > best) { best = v; am = t; }  // first maximum (torch CPU max(1)[1])
+        }
+        const float qn = q_nt[(size_t)b * T + am];
+        const float y1 = qn * gamma + r_step[b] * 0.1f;
+        const float y2 = r_done[b] * 0.1f;
+        int a = (int)action[b];
+        a = min(max(a, 0), T - 1);
+        const float qsa = q_s[(size_t)b * T + a];
+        const float e1 = qsa - y1, e2 = qsa - y2;
+        l += e1 * e1 + e2 * e2;
+        const float d = (2.0f / (float)B) * (e1 + e2);
+        dq[b] = d;
+        sdq += d;
+    }
+    red[0][threadIdx.x] = l;
+    red[1][threadIdx.x] = sdq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *loss = red[0][0] / (float)B;
+        *db4 = red[1][0];
+    }
+}
+
+// per sample b (grid B, 128 threads): the decoder backward touches only row (b, action[b])
+__global__ __launch_bounds__(128) void dec_bwd_rows_kernel(const float* __restrict__ prm, const float* __restrict__ dq,
+                                                           const int64_t* __restrict__ action, const float* __restrict__ d1,
+                                                           const float* __restrict__ hs, int T, float* __restrict__ dd1c,
+                                                           float* __restrict__ w4term, float* __restrict__ hcc) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    int a = (int)action[b];
+    a = min(max(a, 0), T - 1);
+    const size_t row = (size_t)b * T + a;
+    const float d = dq[b], v = d1[row * HD + j];
+    w4term[(size_t)b * HD + j] = d * v;
+    dd1c[(size_t)b * HD + j] = (v > 0.f) ? d * prm[O_W4 + j] : 0.f;
+    hcc[(size_t)b * 256 + j] = fmaxf(hs[row * 256 + j], 0.f);
+    hcc[(size_t)b * 256 + HD + j] = fmaxf(hs[row * 256 + HD + j], 0.f);
+}
+
+struct DqnWs {
+    FwdBufs pol, tgt;
+    float *xcat, *dq, *dd1c, *w4term, *hcc, *dhc, *dG, *dgx, *de, *da1, *slabs;
+};
+
+static constexpr int WG_SPLIT = 16;
+
+static size_t dqn_ws_floats(int B, int T) {
+    const size_t r = (size_t)B * T;
+    size_t n = fwd_bufs_floats(2 * B, T, B) + fwd_bufs_floats(B, T, 0);
+    n += 2 * r * 2;                        // xcat
+    n += B + (size_t)B * 128 * 2 + (size_t)B * 256 * 2;  // dq, dd1c, w4term, hcc, dhc
+    n += 2 * r * 512 + r * 512 + r * 128 + r * 128;       // dG, dgx, de, da1
+    n += (size_t)WG_SPLIT * 512 * 128;     // split-K slabs
+    return n + 64 * 32;
+}
+
+}  // namespace ivosw
+
+using namespace ivosw;
+
+extern "C" size_t ivosw_brain_ws_bytes(int N, int T) {
+    if (N <= 0 || T <= 0) return 0;
+    return fwd_bufs_floats(N, T, 0) * sizeof(float);
+}
+
+extern "C" int ivosw_brain_forward(const float* params, const float* x, int N, int T, float* q, void* ws,
+                                   size_t ws_bytes, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(params && x && q && ws, "null pointer");
+    IVOSW_REQUIRE(N > 0 && T > 0, "N and T must be positive");
+    if (ws_bytes < ivosw_brain_ws_bytes(N, T)) {
+        set_error("ivosw_brain_forward: workspace %zu < %zu", ws_bytes, ivosw_brain_ws_bytes(N, T));
+        return IVOSW_ERR_WS;
+    }
+    hipStream_t st = as_stream(stream);
+    Arena ar(ws);
+    FwdBufs b = carve_fwd(ar, N, T, -1);
+    brain_forward_internal(params, x, N, T, b, st);
+    (void)hipMemcpyAsync(q, b.q, (size_t)N * T * sizeof(float), hipMemcpyDeviceToDevice, st);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+__global__ void argmax_rows_kernel(const float* __restrict__ q, int N, int T, int64_t* __restrict__ idx) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* r = q + (size_t)n * T;
+    int am = 0;
+    float best = r[0];
+    for (int t = 1; t < T; ++t)
+        if (r[t] > best) { best = r[t]; am = t; }
+    idx[n] = am;
+}
+
+extern "C" int ivosw_brain_argmax(const float* q, int N, int T, int64_t* idx, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(q && idx, "null pointer");
+    IVOSW_REQUIRE(N > 0 && T > 0, "N and T must be positive");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), q, N, T, idx);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+extern "C" size_t ivosw_dqn_ws_bytes(int B, int T) {
+    if (B <= 0 || T <= 0) return 0;
+    return dqn_ws_floats(B, T) * sizeof(float);
+}
+
+extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, const float* state,
+                                   const float* new_state, const int64_t* action, const float* reward_step,
+                                   const float* reward_done, int B, int T, float gamma, float* grads, float* loss,
+                                   void* ws, size_t ws_bytes, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(policy && target && state && new_state && action && reward_step && reward_done && grads && loss && ws,
+                  "null pointer");
+    IVOSW_REQUIRE(B > 0 && T > 0, "B and T must be positive");
+    if (ws_bytes < ivosw_dqn_ws_bytes(B, T)) {
+        set_error("ivosw_dqn_loss_grad: workspace %zu < %zu", ws_bytes, ivosw_dqn_ws_bytes(B, T));
+        return IVOSW_ERR_WS;
+    }
+    hipStream_t st = as_stream(stream);
+    const int rows = B * T;
+    Arena ar(ws);
+    DqnWs w{};
+    w.pol = carve_fwd(ar, 2 * B, T, B);   // samples [0,B) = s', [B,2B) = s (kept for backward)
+    w.tgt = carve_fwd(ar, B, T, -1);
+    w.xcat = ar.take<float>((size_t)2 * rows * 2);
+    w.dq = ar.take<float>(B);
+    w.dd1c = ar.take<float>((size_t)B * 128);
+    w.w4term = ar.take<float>((size_t)B * 128);
+    w.hcc = ar.take<float>((size_t)B * 256);
+    w.dhc = ar.take<float>((size_t)B * 256);
+    w.dG = ar.take<float>((size_t)2 * rows * 512);
+    w.dgx = ar.take<float>((size_t)rows * 512);
+    w.de = ar.take<float>((size_t)rows * 128);
+    w.da1 = ar.take<float>((size_t)rows * 128);
+    w.slabs = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
+
+    // ---- forward: policy on [s'; s] in one batch, target on s' (agent.py:135-137,144)
+    (void)hipMemcpyAsync(w.xcat, new_state, (size_t)rows * 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(w.xcat + (size_t)rows * 2, state, (size_t)rows * 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    brain_forward_internal(policy, w.xcat, 2 * B, T, w.pol, st);
+    brain_forward_internal(target, new_state, B, T, w.tgt, st);
+
+    // ---- head: Double-DQN targets, loss, dL/dQsa (agent.py:136-151)
+    const float* q_np = w.pol.q;
+    const float* q_s = w.pol.q + rows;
+    hipLaunchKernelGGL(dqn_head_kernel, dim3(1), dim3(256), 0, st, q_np, w.tgt.q, q_s, action, reward_step, reward_done,
+                       B, T, gamma, w.dq, loss, grads + O_B4);
+
+    // ---- decoder backward on the B rows that carry loss
+    const float* d1_s = w.pol.d1 + (size_t)rows * 128;
+    const float* hs_s = w.pol.hs + (size_t)rows * 256;
+    hipLaunchKernelGGL(dec_bwd_rows_kernel, dim3(B), dim3(128), 0, st, policy, w.dq, action, d1_s, hs_s, T, w.dd1c,
+                       w.w4term, w.hcc);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.w4term, B, 128, 128, grads + O_W4);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.dd1c, B, 128, 128, grads + O_B3);
+    GemmF32 g{};
+    // dW3[128,256] = dd1c^T * hcc
+    g.A = w.dd1c; g.sam = 1; g.sak = 128; g.B = w.hcc; g.sbk = 256; g.sbn = 1; g.C = grads + O_W3; g.ldc = 256;
+    g.M = 128; g.N = 256; g.K = B; g.splitk = 1;
+    launch_gemm_f32(g, st);
+    // dhc[B,256] = (dd1c * W3) . (hcat > 0)
+    g = GemmF32{};
+    g.A = w.dd1c; g.sam = 128; g.sak = 1; g.B = policy + O_W3; g.sbk = 256; g.sbn = 1; g.C = w.dhc; g.ldc = 256;
+    g.M = B; g.N = 256; g.K = 128; g.mask = w.hcc; g.splitk = 1;
+    launch_gemm_f32(g, st);
+
+    // ---- BPTT through the shared cell
+    LstmBwd lb{};
+    lb.whh = policy + O_WHH; lb.gates = w.pol.gates; lb.cs = w.pol.cs; lb.dhc = w.dhc; lb.action = action; lb.dG = w.dG;
+    lb.N = B; lb.T = T;
+    {
+        const int R = rows_per_wg(2 * B);
+        const int nwg = (2 * B + R - 1) / R;
+        if (R == 1) hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3(nwg), dim3(512), 0, st, lb);
+        else if (R == 2) hipLaunchKernelGGL(lstm_bwd_kernel<2>, dim3(nwg), dim3(512), 0, st, lb);
+        else hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3(nwg), dim3(512), 0, st, lb);
+    }
+    // dWhh[512,128] = sum_{d,n,t} dG^T * hprev          (K = 2*B*T)
+    g = GemmF32{};
+    g.A = w.dG; g.sam = 1; g.sak = 512; g.B = w.pol.hprev; g.sbk = 128; g.sbn = 1; g.ldc = 128;
+    g.M = 512; g.N = 128; g.K = 2 * rows;
+    launch_gemm_f32_splitk(g, grads + O_WHH, w.slabs, WG_SPLIT, st);
+    // dgx = dG[fw] + dG[bw]  (the same e_t feeds both directions)
+    {
+        const size_t n = (size_t)rows * 512;
+        hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.dG, w.dG + n, w.dgx, n);
+    }
+    const float* e_s = w.pol.e + (size_t)rows * 128;
+    const float* a1_s = w.pol.a1 + (size_t)rows * 128;
+    // dWih[512,128] = dgx^T * e
+    g = GemmF32{};
+    g.A = w.dgx; g.sam = 1; g.sak = 512; g.B = e_s; g.sbk = 128; g.sbn = 1; g.ldc = 128;
+    g.M = 512; g.N = 128; g.K = rows;
+    launch_gemm_f32_splitk(g, grads + O_WIH, w.slabs, WG_SPLIT, st);
+    // de[rows,128] = dgx * Wih
+    g = GemmF32{};
+    g.A = w.dgx; g.sam = 512; g.sak = 1; g.B = policy + O_WIH; g.sbk = 128; g.sbn = 1; g.C = w.de; g.ldc = 128;
+    g.M = rows; g.N = 128; g.K = 512; g.splitk = 1;
+    launch_gemm_f32(g, st);
+    // dW2[128,128] = de^T * a1 ; db2 = colsum(de)
+    g = GemmF32{};
+    g.A = w.de; g.sam = 1; g.sak = 128; g.B = a1_s; g.sbk = 128; g.sbn = 1; g.ldc = 128;
+    g.M = 128; g.N = 128; g.K = rows;
+    launch_gemm_f32_splitk(g, grads + O_W2, w.slabs, WG_SPLIT, st);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.de, rows, 128, 128, grads + O_B2);
+    // da1[rows,128] = (de * W2) . (a1 > 0)
+    g = GemmF32{};
+    g.A = w.de; g.sam = 128; g.sak = 1; g.B = policy + O_W2; g.sbk = 128; g.sbn = 1; g.C = w.da1; g.ldc = 128;
+    g.M = rows; g.N = 128; g.K = 128; g.mask = a1_s; g.splitk = 1;
+    launch_gemm_f32(g, st);
+    // dW1[128,2] = da1^T * x ; db1 = colsum(da1)
+    g = GemmF32{};
+    g.A = w.da1; g.sam = 1; g.sak = 128; g.B = state; g.sbk = 2; g.sbn = 1; g.ldc = 2;
+    g.M = 128; g.N = 2; g.K = rows;
+    launch_gemm_f32_splitk(g, grads + O_W1, w.slabs, WG_SPLIT, st);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.da1, rows, 128, 128, grads + O_B1);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}

@@ -1,0 +1,106 @@
+// Shared host/device helpers for libivosw_hip.so (gfx950 only; wavefront = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ivosw.h"
+
+namespace ivosw {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(ivosw_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define IVOSW_REQUIRE(cond, msg)                                   \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            ::ivosw::set_error("%s: %s", __func__, msg);           \
+            return IVOSW_ERR_ARG;                                  \
+        }                                                          \
+    } while (0)
+
+#define IVOSW_CHECK_LAUNCH()                                                        \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            ::ivosw::set_error("%s: HIP error %s", __func__, hipGetErrorString(e__)); \
+            return IVOSW_ERR_LAUNCH;                                                \
+        }                                                                           \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided workspace.
+struct Arena {
+    char* base;
+    size_t off;
+    explicit Arena(void* p) : base(static_cast<char*>(p)), off(0) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+// ---------------------------------------------------------------- device helpers
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
+    static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float to_f32(bf16_t v) { return bf16_to_f32(v); }
+    static __device__ __forceinline__ bf16_t from_f32(float v) { return f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// branch-free tanh (ocml tanhf branches, which makes hipcc split the recurrence's fma chains across
+// basic blocks and spill W_hh): saturates correctly, |abs err| ~1e-7
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f); }
+
+// XCD-aware bijective remap of a linear block id: consecutive *logical* ids land on the same XCD
+// (hardware round-robins physical ids over the 8 XCDs), so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    constexpr int NXCD = 8;
+    const int q = nwg / NXCD, r = nwg % NXCD;
+    const int xcd = bid % NXCD, slot = bid / NXCD;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+}  // namespace ivosw

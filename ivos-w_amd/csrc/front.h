@@ -1,0 +1,13 @@
+// Internal launchers shared between assess_front.hip and assess.hip.
+#pragma once
+#include "common.h"
+
+namespace ivosw {
+struct RoiNorm {
+    float mean[3];
+    float std[3];
+};
+void launch_mask_bbox(const float* tp, int B, int H, int W, float* yxhw, int32_t* scratch, hipStream_t st);
+void launch_roi_sample(const float* tf, const float* tp, const float* yxhw, int B, int H, int W, int dtype,
+                       const RoiNorm& nrm, void* roi, hipStream_t st);
+}  // namespace ivosw

@@ -1,0 +1,268 @@
+"""Double-DQN frame-recommendation agent on the MI355X — drop-in for the reference's ``models.agent``.
+
+Same class surface as /root/reference/models/agent.py (``Brain`` :13-64, ``Agent`` :67-236), with the
+arithmetic replaced by libivosw_hip.so:
+
+  Brain.forward        -> ivosw_brain_forward   (batched encoder/gate GEMMs + register-resident LSTM recurrence)
+  Agent.update_agent   -> ivosw_dqn_loss_grad   (3 forwards, two-MSE Double-DQN loss, hand-derived BPTT)
+                          [+ RCCL all-reduce of the flat gradient arena when torch.distributed is up]
+                          ivosw_clamp_adam       (clamp [-1,1] + coupled-L2 Adam, one fused kernel)
+                          ivosw_copy_f32         (hard target sync)
+  Agent.action         -> ivosw_brain_forward + ivosw_brain_argmax (first max, like numpy)
+
+torch modules (nn.Linear / nn.LSTMCell) are used only as parameter containers so that ``state_dict()`` keys,
+shapes and default initialisation are the reference's; their ``forward`` is never called.  All ten tensors are
+views into one flat fp32 arena (``Brain.flat``), which is what the C ABI, Adam and the all-reduce operate on.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .momory_pool import ReplayMemory
+
+_ORDER = ("encoder_fc1.weight", "encoder_fc1.bias", "encoder_fc2.weight", "encoder_fc2.bias",
+          "lstm_cell.weight_ih", "lstm_cell.weight_hh", "decoder_fc1.weight", "decoder_fc1.bias",
+          "decoder_fc2.weight", "decoder_fc2.bias")
+
+
+class Brain(nn.Module):
+    def __init__(self, lstm_input_channels=128, hidden_channels=128, num_fc_concat=128):
+        super().__init__()
+        if (lstm_input_channels, hidden_channels, num_fc_concat) != (128, 128, 128):
+            raise ValueError("the HIP Brain is specialised for the reference's 128/128/128 widths")
+        self.input_channels, self.hidden_channels, self.num_fc_concat = 128, 128, 128
+        # parameter containers, created in the reference's order so a seeded init matches it
+        self.encoder_fc1 = nn.Linear(2, 128)
+        self.encoder_fc2 = nn.Linear(128, 128)
+        self.lstm_cell = nn.LSTMCell(128, 128, False)
+        self.decoder_fc1 = nn.Linear(256, 128)
+        self.decoder_fc2 = nn.Linear(128, 1)
+        self.flat = None
+        self.flat_grad = None
+        self._ws = L.Workspace()
+        self._pack()
+
+    # ------------------------------------------------------------------ flat arena
+    def _named(self):
+        table = dict(self.named_parameters())
+        return [table[k] for k in _ORDER]
+
+    def _pack(self):
+        """(Re)build the flat arena and make every parameter (and its .grad) a view into it."""
+        params = self._named()
+        dev = params[0].device
+        flat = torch.empty(L.BRAIN_NPARAMS, dtype=torch.float32, device=dev)
+        grad = torch.zeros(L.BRAIN_NPARAMS, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).float())
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = grad[off:off + n].view(p.shape)
+            off += n
+        assert off == L.BRAIN_NPARAMS
+        self.flat, self.flat_grad = flat, grad
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._pack()
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input):
+        """input [N,T,2] -> Q [N,T].  Inference only (the DQN update has its own fused backward)."""
+        x = input.detach().to(dtype=torch.float32).contiguous()
+        N, T, P = x.shape
+        assert P == 2
+        q = torch.empty(N, T, dtype=torch.float32, device=x.device)
+        lib = L.lib()
+        nbytes = lib.ivosw_brain_ws_bytes(N, T)
+        ws = self._ws.get(nbytes, x.device)
+        L.check(lib.ivosw_brain_forward(L.dptr(self.flat), L.dptr(x), N, T, L.dptr(q), L.dptr(ws), nbytes,
+                                        L.stream_ptr(x.device)), "brain_forward")
+        return q
+
+
+class FusedClampAdam:
+    """``optim.Adam(params, lr, weight_decay)`` + the reference's grad clamp, as one kernel over the flat arena."""
+
+    def __init__(self, brain, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, clamp=1.0):
+        self.brain = brain
+        self.param_groups = [dict(params=list(brain.parameters()), lr=lr, betas=betas, eps=eps,
+                                  weight_decay=weight_decay, clamp=clamp)]
+        self.state = dict(step=0, exp_avg=None, exp_avg_sq=None)
+        self.grad_scale = 1.0
+
+    def _ensure(self):
+        flat = self.brain.flat
+        if self.state["exp_avg"] is None or self.state["exp_avg"].device != flat.device:
+            self.state["exp_avg"] = torch.zeros_like(flat)
+            self.state["exp_avg_sq"] = torch.zeros_like(flat)
+
+    def zero_grad(self, set_to_none=False):
+        self.brain.flat_grad.zero_()
+
+    def step(self):
+        self._ensure()
+        g = self.param_groups[0]
+        self.state["step"] += 1
+        b = self.brain
+        L.check(L.lib().ivosw_clamp_adam(L.dptr(b.flat), L.dptr(b.flat_grad), L.dptr(self.state["exp_avg"]),
+                                         L.dptr(self.state["exp_avg_sq"]), L.BRAIN_NPARAMS, self.state["step"],
+                                         g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                                         g["clamp"], self.grad_scale, L.stream_ptr(b.flat.device)), "clamp_adam")
+
+    def state_dict(self):
+        self._ensure()
+        return dict(state={k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state.items()},
+                    param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        self._ensure()
+        self.state["step"] = int(sd["state"]["step"])
+        self.state["exp_avg"].copy_(sd["state"]["exp_avg"])
+        self.state["exp_avg_sq"].copy_(sd["state"]["exp_avg_sq"])
+
+
+class Agent(nn.Module):
+    def __init__(self, device, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.device = device
+        a = cfg.agent
+        self.memory_size = a.memory_size
+        self.GAMMA = a.gamma
+        self.EPS_START, self.EPS_END, self.EPS_DECAY = a.eps_start, a.eps_end, a.eps_decay
+        self.steps_done = 0
+        self.update_rate = a.update_rate
+        self.subset = cfg.data.subset
+        self.memory_pool = ReplayMemory(self.memory_size)
+
+        self.policy_net = Brain()
+        self.target_net = Brain()
+        self.target_net.load_state_dict(self.policy_net.state_dict())
+        self.policy_net.to(self.device)
+        self.target_net.to(self.device)
+
+        self.loss = []
+        self.loss_position = 0
+        self.loss_capacity = 32
+        self.loss_avg = 0
+        self.optimizer = FusedClampAdam(self.policy_net, lr=a.lr, weight_decay=a.weight_decay)
+        self._ws = L.Workspace()
+        self._loss_dev = None
+
+    # ------------------------------------------------------------------ data-parallel hook
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist, dist.get_world_size()
+        return None, 1
+
+    # ------------------------------------------------------------------ DQN update
+    def _device_batch(self, sample):
+        """Collated DataLoader dict (datasets/agent_dataset.py) or a DeviceReplay.sample() dict -> device tensors."""
+        dev = self.device
+        if "state" in sample:                       # already gathered on device (ivosw_replay_gather)
+            return (sample["state"], sample["new_state"], sample["action"], sample["reward_step"],
+                    sample["reward_done"])
+        B = sample["action"].shape[0]
+        col = lambda k: torch.as_tensor(sample[k]).reshape(B, -1).to(torch.float32)
+        state = torch.stack([col("old_state_iou"), col("annotated_frames")], 2).contiguous().to(dev)
+        new_state = torch.stack([col("new_state_iou"), col("next_annotated_frames")], 2).contiguous().to(dev)
+        action = torch.as_tensor(sample["action"]).reshape(B).to(torch.int64).to(dev)
+        r_step = torch.as_tensor(sample["reward_step"]).reshape(B).to(torch.float32).to(dev)
+        r_done = torch.as_tensor(sample["reward_done"]).reshape(B).to(torch.float32).to(dev)
+        return state, new_state, action, r_step, r_done       # 'done' is loaded but unused upstream (agent.py:114)
+
+    def loss_and_grads(self, sample):
+        """Forward x3 + loss + backward into policy_net.flat_grad (unclamped). Returns the device loss scalar."""
+        state, new_state, action, r_step, r_done = self._device_batch(sample)
+        B, T, _ = state.shape
+        lib = L.lib()
+        nbytes = lib.ivosw_dqn_ws_bytes(B, T)
+        ws = self._ws.get(nbytes, state.device)
+        if self._loss_dev is None or self._loss_dev.device != state.device:
+            self._loss_dev = torch.zeros(1, dtype=torch.float32, device=state.device)
+        pn, tn = self.policy_net, self.target_net
+        L.check(lib.ivosw_dqn_loss_grad(L.dptr(pn.flat), L.dptr(tn.flat), L.dptr(state), L.dptr(new_state),
+                                        L.dptr(action, torch.int64), L.dptr(r_step), L.dptr(r_done), B, T,
+                                        float(np.float32(self.GAMMA)), L.dptr(pn.flat_grad), L.dptr(self._loss_dev),
+                                        L.dptr(ws), nbytes, L.stream_ptr(state.device)), "dqn_loss_grad")
+        return self._loss_dev
+
+    def update_agent(self, sample):
+        if sample is None:
+            print("no input")
+            return
+        loss = self.loss_and_grads(sample)
+        dist, world = self._world()
+        if world > 1:
+            # synchronous data parallel: sum over ranks (RCCL over xGMI), average inside the Adam kernel;
+            # the clamp therefore sees the averaged gradient, as a single large batch would
+            dist.all_reduce(self.policy_net.flat_grad)
+            self.optimizer.grad_scale = 1.0 / world
+        self._update_avg_loss(loss)
+        self.optimizer.step()
+        # hard target sync with probability update_rate; np.random is seeded identically on every rank
+        if np.random.random() < self.update_rate:
+            print("target_net updated!")
+            self.sync_target()
+        return self.loss[(self.loss_position - 1) % self.loss_capacity]
+
+    def sync_target(self):
+        pn, tn = self.policy_net, self.target_net
+        L.check(L.lib().ivosw_copy_f32(L.dptr(tn.flat), L.dptr(pn.flat), L.BRAIN_NPARAMS,
+                                       L.stream_ptr(pn.flat.device)), "copy_f32")
+
+    # ------------------------------------------------------------------ acting
+    def action(self, state, verbose=True):
+        self.steps_done += 1
+        if self.cfg.phase != "train":
+            eps_threshold = 0
+        else:
+            eps_threshold = self.EPS_END + (self.EPS_START - self.EPS_END) * \
+                math.exp(-0.5 * self.steps_done / self.EPS_DECAY)
+        n_frames = np.asarray(state).shape[0]
+        rand_flag = random.random()
+        greedy = rand_flag > eps_threshold
+        if verbose:
+            print(f"step:{self.steps_done}, rand_flag:{rand_flag:.4f}, eps_threshold:{eps_threshold:.4f}, "
+                  f"frame index was selected {'by agent' if greedy else 'randomly'}")
+        if not greedy:
+            return random.choice(np.array(range(n_frames)))
+        x = torch.as_tensor(np.asarray(state)[np.newaxis], dtype=torch.float32).to(self.device)
+        q = self.policy_net(x)
+        idx = torch.empty(1, dtype=torch.int64, device=q.device)
+        L.check(L.lib().ivosw_brain_argmax(L.dptr(q), 1, q.shape[1], L.dptr(idx), L.stream_ptr(q.device)), "argmax")
+        return np.int64(idx.item())
+
+    # ------------------------------------------------------------------ bookkeeping
+    def _update_avg_loss(self, loss):
+        if len(self.loss) < self.loss_capacity:
+            self.loss.append(None)
+        self.loss[self.loss_position] = float(loss.detach().to("cpu").reshape(-1)[0])
+        self.loss_position = (self.loss_position + 1) % self.loss_capacity
+        self.loss_avg = sum(self.loss) / len(self.loss)
+
+    def get_avg_loss(self):
+        return self.loss_avg
+
+    def set_train(self):
+        self.policy_net.train()
+        self.target_net.train()
+
+    def set_eval(self):
+        self.policy_net.eval()
+        self.target_net.eval()
+
+    def memory(self, state, old_frame, next_state, reward_step, reward_done, is_done, state_iou, next_state_iou,
+               annotated_frames_str, next_annotated_frames_str, report_save_dir):
+        self.memory_pool.push(state, old_frame, next_state, reward_step, reward_done, is_done, state_iou,
+                              next_state_iou, annotated_frames_str, next_annotated_frames_str)
+        self.memory_pool.push_to_csv(report_save_dir)

@@ -1,0 +1,161 @@
+"""Replay memory with the reference's class surface and CSV persistence format.
+
+Mirrors /root/reference/models/momory_pool.py:8-162 (``Transition`` field order, ``ReplayMemory`` ring with
+``position`` starting at -1, ``memory_pool.csv`` schema = index column + 12 columns, the per-sequence
+``sample_th`` filter and the capacity shrink in ``load_from_csv``).  The module name keeps the reference's
+spelling ("momory") so imports drop in.  ``DeviceReplay`` is the MI355X-side addition: the same rows as a
+device-resident SoA that ``ivosw_replay_gather`` samples minibatches from.
+"""
+import os
+import random
+from collections import namedtuple
+
+import numpy as np
+import pandas as pd
+
+Transition = namedtuple("Transition", ["state", "action", "next_state", "reward_step", "reward_done", "done",
+                                       "state_iou", "next_state_iou", "annotated_frames", "next_annotated_frames"])
+
+_CSV_COLUMNS = ("sequence", "scribble_iter", "n_interaction", "n_interaction_next", "action", "reward_step",
+                "reward_done", "done", "state_iou", "next_state_iou", "annotated_frames", "next_annotated_frames")
+
+
+def _mean_of_joined(strings):
+    """'a/b/c' strings -> per-row mean (float64)."""
+    return np.array([[float(tok) for tok in s.split("/")] for s in strings], dtype=np.float64).mean(axis=1)
+
+
+class ReplayMemory:
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.memory = []
+        self.position = -1            # first push lands on slot 0
+        self.basename_csv = "memory_pool.csv"
+        self.COLUMNS = list(_CSV_COLUMNS)
+        self.memory_pd = pd.DataFrame(columns=self.COLUMNS)
+        self.seq_list = []
+
+    def __len__(self):
+        return len(self.memory)
+
+    # ------------------------------------------------------------------ ring
+    def push(self, *fields):
+        if len(self.memory) < self.capacity:
+            self.memory.append(None)
+        self.position = (self.position + 1) % self.capacity
+        self.memory[self.position] = Transition(*fields)
+
+    def random_sample(self, batch_size):
+        """Unused by the reference's training loop (minibatches come from the CSV), kept for the surface."""
+        if batch_size > len(self.memory):
+            return None
+        picked = random.sample(self.memory, batch_size)
+        return Transition(*zip(*picked))
+
+    # ------------------------------------------------------------------ CSV
+    def load_from_csv(self, path_to_random_memory_csv, report_save_dir=None, sample_th=0):
+        frame = pd.read_csv(path_to_random_memory_csv, index_col=0)[:self.capacity]
+        names = frame["sequence"].tolist()
+        ordered_unique = list(dict.fromkeys(names))           # first-occurrence order
+        if sample_th > 0:
+            assert sample_th < 1
+            self.seq_list = []
+            for seq in ordered_unique:
+                rows = frame[frame.sequence == seq]
+                if len(rows) == 0:
+                    continue
+                lo = _mean_of_joined(rows.state_iou.values.tolist()).min()
+                hi = _mean_of_joined(rows.next_state_iou.values.tolist()).max()
+                if hi - lo > sample_th:
+                    self.seq_list.append(seq)
+            print(f"the number of available samples under threshold {sample_th}: {len(self.seq_list)}")
+        else:
+            self.seq_list.extend(ordered_unique)
+
+        cols = {c: frame[c].tolist() for c in self.COLUMNS}
+        kept = 0
+        allowed = set(self.seq_list)
+        for i in range(min(len(names), self.capacity)):
+            if sample_th > 0:
+                assert len(self.seq_list) > 0
+                if names[i] not in allowed:
+                    continue
+            kept += 1
+            where = dict(sequence=names[i], scribble_iter=cols["scribble_iter"][i])
+            self.push(dict(where, n_interaction=cols["n_interaction"][i]), cols["action"][i],
+                      dict(where, n_interaction=cols["n_interaction_next"][i]), cols["reward_step"][i],
+                      cols["reward_done"][i], cols["done"][i], cols["state_iou"][i], cols["next_state_iou"][i],
+                      cols["annotated_frames"][i], cols["next_annotated_frames"][i])
+        self.capacity = kept           # the reference shrinks the ring to what it kept (:110)
+
+        os.makedirs(report_save_dir, exist_ok=True)
+        self.memory_pd = frame[:self.capacity]
+        self.memory_pd.to_csv(os.path.join(report_save_dir, self.basename_csv))
+
+    def _row_at(self, pos):
+        t = self.memory[pos]
+        return {"sequence": t.state["sequence"], "scribble_iter": t.state["scribble_iter"],
+                "n_interaction": t.state["n_interaction"], "n_interaction_next": t.next_state["n_interaction"],
+                "action": t.action, "reward_step": t.reward_step, "reward_done": t.reward_done, "done": t.done,
+                "state_iou": t.state_iou, "next_state_iou": t.next_state_iou,
+                "annotated_frames": t.annotated_frames, "next_annotated_frames": t.next_annotated_frames}
+
+    def push_to_csv(self, report_save_dir):
+        """Append the most recent transition to the CSV image (dropping the oldest row when over capacity)
+        and rewrite ``memory_pool.csv`` — same file content as the reference (:126-153)."""
+        row = pd.DataFrame(data={k: [v] for k, v in self._row_at(self.position).items()}, columns=self.COLUMNS)
+        self.memory_pd = pd.concat([self.memory_pd, row], ignore_index=True)
+        if len(self.memory_pd) > self.capacity:
+            self.memory_pd = self.memory_pd.drop(self.memory_pd.index.min())
+        self.memory_pd.to_csv(os.path.join(report_save_dir, self.basename_csv))
+
+
+def parse_rows(frame, T=None):
+    """CSV frame -> SoA numpy dict (float64 [n,T] columns, int64/float64/bool scalars) — the arithmetic content
+    of datasets/agent_dataset.py:71-115 without per-sample python objects."""
+    def mat(col):
+        return np.array([[float(tok) for tok in str(s).split("/")] for s in frame[col].tolist()], dtype=np.float64)
+    out = dict(action=frame["action"].to_numpy(np.int64), reward_step=frame["reward_step"].to_numpy(np.int64),
+               reward_done=frame["reward_done"].to_numpy(np.float64), done=frame["done"].to_numpy(bool),
+               old_state_iou=mat("state_iou"), new_state_iou=mat("next_state_iou"),
+               annotated_frames=mat("annotated_frames"), next_annotated_frames=mat("next_annotated_frames"))
+    if T is not None:
+        assert out["old_state_iou"].shape[1] == T
+    return out
+
+
+class DeviceReplay:
+    """Device-resident SoA replay buffer; ``sample(idx)`` gathers a minibatch with ``ivosw_replay_gather``."""
+
+    def __init__(self, soa, device):
+        import torch
+        from .. import _lib
+        self._lib = _lib
+        self.device = torch.device(device)
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(self.device).contiguous()
+        self.old_iou, self.new_iou = f32(soa["old_state_iou"]), f32(soa["new_state_iou"])
+        self.ann, self.next_ann = f32(soa["annotated_frames"]), f32(soa["next_annotated_frames"])
+        self.action = torch.as_tensor(soa["action"], dtype=torch.int64).to(self.device)
+        self.reward_step = f32(soa["reward_step"])
+        self.reward_done = f32(soa["reward_done"])
+        self.n, self.T = self.old_iou.shape
+
+    def __len__(self):
+        return self.n
+
+    def sample(self, idx):
+        """idx: int64 device tensor [B] -> dict of device tensors (state/new_state [B,T,2] fp32, ...)."""
+        import torch
+        L = self._lib
+        B = idx.numel()
+        state = torch.empty(B, self.T, 2, dtype=torch.float32, device=self.device)
+        new_state = torch.empty_like(state)
+        act = torch.empty(B, dtype=torch.int64, device=self.device)
+        rs = torch.empty(B, dtype=torch.float32, device=self.device)
+        rd = torch.empty_like(rs)
+        L.check(L.lib().ivosw_replay_gather(
+            L.dptr(self.old_iou), L.dptr(self.new_iou), L.dptr(self.ann), L.dptr(self.next_ann), L.dptr(self.action),
+            L.dptr(self.reward_step), L.dptr(self.reward_done), L.dptr(idx, torch.int64), B, self.T,
+            L.dptr(state), L.dptr(new_state), L.dptr(act), L.dptr(rs), L.dptr(rd), L.stream_ptr(self.device)),
+            "replay_gather")
+        return dict(state=state, new_state=new_state, action=act, reward_step=rs, reward_done=rd)

@@ -1,0 +1,156 @@
+"""GPU parity: HIP Brain / DQN step (through the C ABI and the drop-in classes) vs the oracle and the
+reference goldens.  Bit-exact argmax; fp32 Q-values, loss, gradients and Adam state within stated tolerances."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ivos_w_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+def cfg(update_rate=0.5, phase="train"):
+    return AD(phase=phase, data=AD(subset="train"),
+              agent=AD(memory_size=1000, gamma=0.95, eps_start=0.7, eps_end=0.25, eps_decay=500,
+                       update_rate=update_rate, lr=5e-6, weight_decay=5e-4))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def load_brain(net, seed):
+    sd = synth.brain_state_dict(seed)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd
+
+
+@pytest.mark.parametrize("i,N,T", [(0, 1, 25), (1, 1, 37), (2, 1, 104), (3, 128, 25), (4, 3, 1), (5, 2, 2)])
+def test_brain_forward_vs_reference_golden(dev, golden_dir, i, N, T):
+    from ivos_w_amd.models.agent import Brain
+    from oracle import brain_oracle as bo
+    g = np.load(os.path.join(golden_dir, "brain_forward.npz"))
+    net = Brain().to(dev)
+    P = load_brain(net, 0)
+    x = synth.brain_inputs(N, T, 100 + i)
+    q = net(torch.Tensor(x).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(q, g[f"q_{N}_{T}"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(q.argmax(1), g[f"argmax_{N}_{T}"])                 # bit-exact recommended frame
+    np.testing.assert_allclose(q, bo.brain_forward(P, x.astype(np.float32)), rtol=1e-4, atol=1e-6)
+
+
+def test_brain_large_batch_vs_oracle(dev):
+    """rows > 512 exercises the multi-row-per-workgroup recurrence."""
+    from ivos_w_amd.models.agent import Brain
+    from oracle import brain_oracle as bo
+    net = Brain().to(dev)
+    P = load_brain(net, 3)
+    x = synth.brain_inputs(300, 25, 9)
+    q = net(torch.Tensor(x).to(dev)).cpu().numpy()
+    ref = bo.brain_forward(P, x.astype(np.float32))
+    np.testing.assert_allclose(q, ref, rtol=1e-4, atol=1e-6)
+    assert np.array_equal(q.argmax(1), ref.argmax(1))
+
+
+def test_action_is_first_argmax(dev, golden_dir):
+    from ivos_w_amd.models.agent import Agent
+    g = np.load(os.path.join(golden_dir, "brain_forward.npz"))
+    agent = Agent(dev, cfg(phase="eval"))
+    load_brain(agent.policy_net, 0)
+    a = agent.action(synth.brain_inputs(1, 104, 102)[0], verbose=False)
+    assert int(a) == int(g["argmax_1_104"][0]) and agent.steps_done == 1
+
+
+@pytest.mark.parametrize("B,T", [(32, 25), (128, 25), (5, 9), (1, 3)])
+def test_loss_and_grads_vs_oracle(dev, B, T):
+    from ivos_w_amd.models.agent import Agent
+    from oracle import brain_oracle as bo
+    tr = synth.replay_transitions(n=500, T=T, seed=11)
+    agent = Agent(dev, cfg())
+    P = load_brain(agent.policy_net, 0)
+    Pt = load_brain(agent.target_net, 1)
+    batch = synth.collate_np(tr, synth.minibatch_indices(0, n=500, B=B, seed=7))
+    loss = agent.loss_and_grads(batch).item()
+    ref_loss, G = bo.dqn_loss_and_grads(P, Pt, batch, 0.95)
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-4)
+    got = agent.policy_net.flat_grad.cpu().numpy()
+    want = synth.brain_flat(G)
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-5 * scale)
+    for k, (off, shp) in synth.brain_offsets().items():       # every tensor individually, relative to its own scale
+        n = int(np.prod(shp))
+        s = np.abs(want[off:off + n]).max() + 1e-30
+        assert np.abs(got[off:off + n] - want[off:off + n]).max() <= 1e-3 * s, k
+
+
+@pytest.mark.parametrize("B", [32, 128])
+def test_three_update_steps_vs_reference_golden(dev, golden_dir, B):
+    from ivos_w_amd.models.agent import Agent
+    g = np.load(os.path.join(golden_dir, "dqn_steps.npz"))
+    tr = synth.replay_transitions(n=2000, T=25, seed=2019)
+    agent = Agent(dev, cfg(update_rate=0.5))
+    load_brain(agent.policy_net, 0)
+    load_brain(agent.target_net, 1)
+    np.random.seed(5)
+    for step in range(3):
+        batch = {k: torch.from_numpy(np.ascontiguousarray(v))
+                 for k, v in synth.collate_np(tr, synth.minibatch_indices(step, n=2000, B=B, seed=7)).items()}
+        before = agent.policy_net.flat.double().cpu().numpy()
+        loss = agent.update_agent(batch)
+        np.testing.assert_allclose(loss, g[f"loss_B{B}_s{step}"], rtol=1e-4)
+        after = agent.policy_net.flat.double().cpu().numpy()
+        m = agent.optimizer.state["exp_avg"].cpu().numpy()
+        v = agent.optimizer.state["exp_avg_sq"].cpu().numpy()
+        for k, (off, shp) in synth.brain_offsets().items():
+            tag = f"B{B}_s{step}_{k}"
+            n = min(64, int(np.prod(shp)))
+            np.testing.assert_allclose((after - before)[off:off + n], g["dslice_" + tag][:n], rtol=5e-3, atol=2e-8, err_msg=tag)
+            n = min(32, int(np.prod(shp)))
+            np.testing.assert_allclose(m[off:off + n], g["m_" + tag][:n], rtol=2e-3, atol=1e-7, err_msg=tag)
+            np.testing.assert_allclose(v[off:off + n], g["v_" + tag][:n], rtol=4e-3, atol=1e-12, err_msg=tag)
+        synced = torch.equal(agent.policy_net.flat, agent.target_net.flat)
+        assert synced == bool(g[f"synced_B{B}_s{step}"])
+    np.testing.assert_allclose(agent.policy_net.flat.cpu().numpy()[::97], g[f"final_B{B}"], rtol=1e-4, atol=1e-7)
+    assert abs(agent.get_avg_loss() - np.mean([g[f"loss_B{B}_s{s}"] for s in range(3)])) < 1e-5
+
+
+def test_replay_gather_and_device_step(dev):
+    from ivos_w_amd.models.agent import Agent
+    from ivos_w_amd.models.momory_pool import DeviceReplay
+    from oracle import brain_oracle as bo
+    tr = synth.replay_transitions(n=1000, T=25, seed=3)
+    rp = DeviceReplay(tr, dev)
+    idx = synth.minibatch_indices(0, n=1000, B=64, seed=7)
+    s = rp.sample(torch.from_numpy(idx).to(dev))
+    st, nst = bo.build_states(synth.collate_np(tr, idx))
+    np.testing.assert_array_equal(s["state"].cpu().numpy(), st)
+    np.testing.assert_array_equal(s["new_state"].cpu().numpy(), nst)
+    np.testing.assert_array_equal(s["action"].cpu().numpy(), tr["action"][idx])
+    agent = Agent(dev, cfg())
+    P, Pt = load_brain(agent.policy_net, 0), load_brain(agent.target_net, 1)
+    loss = agent.loss_and_grads(s).item()
+    ref, _ = bo.dqn_loss_and_grads(P, Pt, synth.collate_np(tr, idx), 0.95)
+    np.testing.assert_allclose(loss, ref, rtol=1e-4)
+
+
+def test_update_agent_none(dev, capsys):
+    from ivos_w_amd.models.agent import Agent
+    assert Agent(dev, cfg()).update_agent(None) is None
+    assert "no input" in capsys.readouterr().out
+
+
+def test_bad_args_fail_loudly(dev):
+    from ivos_w_amd import _lib as L
+    from ivos_w_amd.models.agent import Brain
+    with pytest.raises(RuntimeError):
+        Brain()(torch.zeros(1, 5, 2))                       # CPU tensor: no fallback
+    rc = L.lib().ivosw_brain_forward(None, None, 1, 1, None, None, 0, None)
+    assert rc < 0 and b"null" in L.lib().ivosw_last_error()
