@@ -1,0 +1,243 @@
+// AssessNet.forward on the MI355X: plan of the 54-conv tower, weight packing, chunked execution.
+//
+// Reference: AssessNet.forward (models/assessment.py:164-182), Encoder (:12-63), torchvision ResNet-50 v1.5.
+// Frames run through the whole tower in chunks (default 32 bf16 / 16 fp32) so that the layer-to-layer
+// activations of a chunk (<= ~2 MB per frame per tensor) stay resident in the 256 MiB Infinity Cache instead
+// of making a round trip to HBM between every pair of layers.
+#include <vector>
+
+#include "conv.h"
+#include "front.h"
+
+namespace ivosw {
+
+struct ConvPlan {
+    int Cin, Cout, K, stride, pad;  // K = kernel size (1 or 3)
+    int t_w, t_bn;                  // state_dict indices: conv weight; bn weight (bias, mean, var follow)
+    size_t w_off, b_off;            // byte offsets into the packed arena
+};
+
+struct BlockPlan {
+    int c1, c2, c3, ds;  // indices into convs (ds = -1 if none)
+};
+
+struct Plan {
+    std::vector<ConvPlan> convs;
+    std::vector<BlockPlan> blocks;
+    size_t norm_off, fcw_off, fcb_off, stem_w_off, stem_b_off, total;
+    int t_stem_w3, t_stem_w1, t_stem_bn, t_fcw, t_fcb, t_mean, t_std;
+};
+
+static Plan make_plan(int dtype) {
+    Plan P;
+    const size_t es = (dtype == IVOSW_BF16) ? 2 : 4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); const size_t o = off; off += bytes; return o; };
+    P.norm_off = take(8 * sizeof(float));
+    P.fcw_off = take(2048 * sizeof(float));
+    P.fcb_off = take(sizeof(float));
+    P.stem_w_off = take((size_t)64 * ((dtype == IVOSW_BF16) ? 256 : 224) * es);
+    P.stem_b_off = take(64 * sizeof(float));
+    // state_dict order: 0 mean, 1 std, 2 conv1_m.w, 3 conv1_m.b, 4 conv1_p.w, 5 conv1_n.w,
+    // 6 conv1.w, 7..11 bn1.{w,b,rm,rv,nbt}, then per block conv1.w, bn1x5, conv2.w, bn2x5, conv3.w, bn3x5,
+    // [downsample.0.w, downsample.1x5], finally fc1.w, fc1.b
+    P.t_mean = 0; P.t_std = 1; P.t_stem_w1 = 4; P.t_stem_w3 = 6; P.t_stem_bn = 7;
+    int t = 12;
+    const int nblk[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512}, strides[4] = {1, 2, 2, 2};
+    int inpl = 64;
+    auto add = [&](int cin, int cout, int k, int stride) {
+        ConvPlan c{};
+        c.Cin = cin; c.Cout = cout; c.K = k; c.stride = stride; c.pad = (k == 3) ? 1 : 0;
+        c.t_w = t; c.t_bn = t + 1; t += 6;
+        c.w_off = take((size_t)cout * k * k * cin * es);
+        c.b_off = take((size_t)cout * sizeof(float));
+        P.convs.push_back(c);
+        return (int)P.convs.size() - 1;
+    };
+    for (int s = 0; s < 4; ++s)
+        for (int b = 0; b < nblk[s]; ++b) {
+            const int st = (b == 0) ? strides[s] : 1;
+            BlockPlan bp{};
+            bp.c1 = add(inpl, planes[s], 1, 1);
+            bp.c2 = add(planes[s], planes[s], 3, st);
+            bp.c3 = add(planes[s], planes[s] * 4, 1, 1);
+            bp.ds = (b == 0) ? add(inpl, planes[s] * 4, 1, st) : -1;
+            P.blocks.push_back(bp);
+            inpl = planes[s] * 4;
+        }
+    P.t_fcw = t; P.t_fcb = t + 1;
+    P.total = align_up(off, 256);
+    return P;
+}
+
+static const Plan& plan_for(int dtype) {
+    static const Plan pb = make_plan(IVOSW_BF16), pf = make_plan(IVOSW_F32);
+    return dtype == IVOSW_BF16 ? pb : pf;
+}
+
+__global__ void copy_small_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float* __restrict__ o) {
+    const int i = threadIdx.x;
+    if (i < na) o[i] = a[i];
+    if (i < nb) o[na + i] = b[i];
+}
+
+// per-frame element counts of the activation buffers
+constexpr size_t E_ROI = 256 * 256 * 4, E_BIG = 64 * 64 * 256, E_MID = 64 * 64 * 128;
+
+static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 32 : 16; }
+
+struct Bufs {
+    float* yxhw; int32_t* box; float* pooled;
+    char *roi, *stem, *p0, *p1, *m1, *m2, *ds;
+};
+
+static size_t carve(Arena& ar, int dtype, int B, int chunk, Bufs* out) {
+    const size_t es = (dtype == IVOSW_BF16) ? 2 : 4;
+    Bufs b{};
+    b.yxhw = ar.take<float>((size_t)B * 4);
+    b.box = ar.take<int32_t>((size_t)B * 4);
+    b.pooled = ar.take<float>((size_t)chunk * 2048);
+    b.roi = ar.take<char>(chunk * E_ROI * es);
+    b.stem = ar.take<char>(chunk * E_BIG * es);
+    b.p0 = ar.take<char>(chunk * E_BIG * es);
+    b.p1 = ar.take<char>(chunk * E_BIG * es);
+    b.ds = ar.take<char>(chunk * E_BIG * es);
+    b.m1 = ar.take<char>(chunk * E_MID * es);
+    b.m2 = ar.take<char>(chunk * E_MID * es);
+    if (out) *out = b;
+    return align_up(ar.off, 256);
+}
+
+}  // namespace ivosw
+
+using namespace ivosw;
+
+extern "C" size_t ivosw_assess_packed_bytes(int dtype) {
+    if (dtype != IVOSW_F32 && dtype != IVOSW_BF16) return 0;
+    return plan_for(dtype).total;
+}
+
+extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* tensors, int ntensors, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(packed && tensors, "null pointer");
+    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
+    IVOSW_REQUIRE(ntensors == IVOSW_ASSESS_NTENSORS, "expected the 326 tensors of AssessNet.state_dict()");
+    const Plan& P = plan_for(dtype);
+    IVOSW_REQUIRE(P.t_fcb == IVOSW_ASSESS_NTENSORS - 1, "internal: plan/state_dict mismatch");
+    hipStream_t st = as_stream(stream);
+    char* base = static_cast<char*>(packed);
+    auto T = [&](int i) { return static_cast<const float*>(tensors[i]); };
+    for (int i : {P.t_mean, P.t_std, P.t_stem_w1, P.t_stem_w3, P.t_fcw, P.t_fcb}) IVOSW_REQUIRE(tensors[i], "null tensor");
+    hipLaunchKernelGGL(copy_small_kernel, dim3(1), dim3(64), 0, st, T(P.t_mean), 3, T(P.t_std), 3,
+                       reinterpret_cast<float*>(base + P.norm_off));
+    (void)hipMemcpyAsync(base + P.fcw_off, T(P.t_fcw), 2048 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(base + P.fcb_off, T(P.t_fcb), sizeof(float), hipMemcpyDeviceToDevice, st);
+    launch_pack_stem(T(P.t_stem_w3), T(P.t_stem_w1), T(P.t_stem_bn), T(P.t_stem_bn + 1), T(P.t_stem_bn + 2),
+                     T(P.t_stem_bn + 3), dtype, base + P.stem_w_off, reinterpret_cast<float*>(base + P.stem_b_off), st);
+    for (const ConvPlan& c : P.convs) {
+        for (int j = 0; j < 4; ++j) IVOSW_REQUIRE(tensors[c.t_bn + j] && tensors[c.t_w], "null tensor");
+        launch_pack_conv(T(c.t_w), T(c.t_bn), T(c.t_bn + 1), T(c.t_bn + 2), T(c.t_bn + 3), c.Cout, c.Cin, c.K, c.K, dtype,
+                         base + c.w_off, reinterpret_cast<float*>(base + c.b_off), st);
+    }
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk) {
+    if ((dtype != IVOSW_F32 && dtype != IVOSW_BF16) || B <= 0 || H <= 0 || W <= 0) return 0;
+    if (chunk <= 0) chunk = default_chunk(dtype);
+    if (chunk > B) chunk = B;
+    Arena ar(nullptr);
+    return carve(ar, dtype, B, chunk, nullptr) + 256;
+}
+
+extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
+    (void)dtype;
+    return "conv_igemm_kernel";
+}
+
+extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp, int B, int H, int W,
+                                    float* scores, void* ws, size_t ws_bytes, int chunk, int tap_stage, void* tap_out,
+                                    ivosw_stream_t stream) {
+    IVOSW_REQUIRE(packed && tf && tp && scores && ws, "null pointer");
+    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
+    IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
+    IVOSW_REQUIRE(tap_stage >= 0 && tap_stage <= 8, "tap_stage out of range");
+    IVOSW_REQUIRE(tap_stage == 0 || tap_out, "tap_out is null");
+    if (chunk <= 0) chunk = default_chunk(dtype);
+    if (chunk > B) chunk = B;
+    IVOSW_REQUIRE(tap_stage == 0 || B <= chunk, "taps need B <= chunk");
+    if (ws_bytes < ivosw_assess_ws_bytes(dtype, B, H, W, chunk)) {
+        set_error("ivosw_assess_forward: workspace %zu < %zu", ws_bytes, ivosw_assess_ws_bytes(dtype, B, H, W, chunk));
+        return IVOSW_ERR_WS;
+    }
+    hipStream_t st = as_stream(stream);
+    const Plan& P = plan_for(dtype);
+    const size_t es = (dtype == IVOSW_BF16) ? 2 : 4;
+    const char* base = static_cast<const char*>(packed);
+    Arena ar(ws);
+    Bufs bf{};
+    carve(ar, dtype, B, chunk, &bf);
+    auto tap = [&](int stage, const void* src, size_t bytes) {
+        if (tap_stage == stage) (void)hipMemcpyAsync(tap_out, src, bytes, hipMemcpyDeviceToDevice, st);
+    };
+
+    // K1/K2: mask -> (y,x,h,w) for the whole batch, on device
+    launch_mask_bbox(tp, B, H, W, bf.yxhw, bf.box, st);
+    // Encoder.mean/std come from the checkpoint: the sampler reads them from the packed arena
+    RoiNorm nrm{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, reinterpret_cast<const float*>(base + P.norm_off)};
+
+    const size_t plane = (size_t)H * W;
+    for (int f0 = 0; f0 < B; f0 += chunk) {
+        const int nb = (B - f0 < chunk) ? B - f0 : chunk;
+        // K3: ROI crop-resize + normalise -> NHWC4
+        launch_roi_sample(tf + (size_t)f0 * 3 * plane, tp + (size_t)f0 * plane, bf.yxhw + (size_t)f0 * 4, nb, H, W, dtype,
+                          nrm, bf.roi, st);
+        tap(1, bf.roi, nb * E_ROI * es);
+        // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool
+        ConvArgs a{};
+        a.x = bf.roi; a.w = base + P.stem_w_off; a.bias = reinterpret_cast<const float*>(base + P.stem_b_off);
+        a.res = nullptr; a.y = bf.stem; a.B = nb; a.H = 256; a.W = 256; a.Cin = 4; a.Ho = 128; a.Wo = 128; a.Cout = 64;
+        a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
+        launch_conv(a, dtype, true, st);
+        tap(2, bf.stem, (size_t)nb * 128 * 128 * 64 * es);
+        launch_maxpool(bf.stem, nb, 128, 128, 64, dtype, bf.p0, st);
+        tap(3, bf.p0, (size_t)nb * 64 * 64 * 64 * es);
+        // K5: 16 bottlenecks
+        char* x = bf.p0;
+        char* y = bf.p1;
+        int hw = 64;
+        int bi = 0;
+        const int nblk[4] = {3, 4, 6, 3};
+        for (int s = 0; s < 4; ++s) {
+            for (int b = 0; b < nblk[s]; ++b, ++bi) {
+                const BlockPlan& bp = P.blocks[bi];
+                const ConvPlan &c1 = P.convs[bp.c1], &c2 = P.convs[bp.c2], &c3 = P.convs[bp.c3];
+                const int ho = hw / c2.stride;
+                auto mk = [&](const ConvPlan& c, const void* in, int hin, int hout, const void* res, void* out, int relu) {
+                    ConvArgs q{};
+                    q.x = in; q.w = base + c.w_off; q.bias = reinterpret_cast<const float*>(base + c.b_off); q.res = res; q.y = out;
+                    q.B = nb; q.H = hin; q.W = hin; q.Cin = c.Cin; q.Ho = hout; q.Wo = hout; q.Cout = c.Cout;
+                    q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
+                    launch_conv(q, dtype, false, st);
+                };
+                mk(c1, x, hw, hw, nullptr, bf.m1, 1);
+                mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
+                const void* idt = x;
+                if (bp.ds >= 0) {
+                    mk(P.convs[bp.ds], x, hw, ho, nullptr, bf.ds, 0);
+                    idt = bf.ds;
+                }
+                mk(c3, bf.m2, ho, ho, idt, y, 1);  // relu(bn3(conv3) + identity)
+                char* t = x; x = y; y = t;
+                hw = ho;
+            }
+            tap(4 + s, x, (size_t)nb * hw * hw * P.convs[P.blocks[bi - 1].c3].Cout * es);
+        }
+        // K6: 8x8 average pool + fc1
+        launch_pool_fc(x, nb, dtype, reinterpret_cast<const float*>(base + P.fcw_off),
+                       reinterpret_cast<const float*>(base + P.fcb_off), scores + f0, tap_stage == 8 ? bf.pooled : nullptr, st);
+        tap(8, bf.pooled, (size_t)nb * 2048 * sizeof(float));
+    }
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}

@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict
         if (vy0 && vx1) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + 1], w_ne));
         if (vy1 && vx0) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + W], w_sw));
         if (vy1 && vx1) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + W + 1], w_se));
-        out[c] = (c < 3) ? __fsub_rn(acc, nrm.mean[c]) / nrm.std[c] : acc;  // (f - mean) / std after the zero pad
+        if (c < 3) {  // (f - mean) / std after the zero pad (assessment.py:47)
+            const float mu = nrm.dev ? nrm.dev[c] : nrm.mean[c], sd = nrm.dev ? nrm.dev[3 + c] : nrm.std[c];
+            acc = __fsub_rn(acc, mu) / sd;
+        }
+        out[c] = acc;
     }
     T* dst = roi + (((size_t)b * 256 + i) * 256 + j) * 4;
     if constexpr (sizeof(T) == 4) {
@@ -184,7 +188,7 @@ extern "C" int ivosw_roi_sample(const float* tf, const float* tp, const float* y
     IVOSW_REQUIRE(tf && tp && yxhw && roi, "null pointer");
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
     IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
-    RoiNorm nrm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}};  // Encoder.mean/std buffers (assessment.py:41-44)
+    RoiNorm nrm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, nullptr};  // Encoder.mean/std (assessment.py:41-44)
     launch_roi_sample(tf, tp, yxhw, B, H, W, dtype, nrm, roi, as_stream(stream));
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;

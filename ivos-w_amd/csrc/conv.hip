@@ -1,0 +1,416 @@
+// Convolution tower kernels for the quality-assessment CNN (K4/K5/K6): NHWC implicit-GEMM convolution on the
+// matrix cores with BN folded into the weights, bias/residual/ReLU fused in the epilogue; stem 7x7 (RGB+mask
+// concatenated along Cin); 3x3/2 max-pool; 8x8 average pool + fc.
+//
+// Reference arithmetic: Encoder.forward (models/assessment.py:46-63) over torchvision's ResNet-50 v1.5
+// bottlenecks, avg_pool2d(.,8) + fc1 (:179-180).
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin.  A K-tile is 128 bytes of one filter tap
+// (64 bf16 / 32 fp32 channels), so an A row is one contiguous 128-B NHWC segment (or zeros at the border)
+// and a B row is 128 B of the K-major packed weights.  Tiles are staged global -> registers -> LDS
+// (double-buffered, one barrier per K-tile, next tile's loads in flight under the MFMAs); the LDS image is
+// XOR-swizzled at 16-B granularity (chunk ^= (row>>1)&7) so both the 8-lane ds_write_b128 groups and the
+// 16-lane ds_read_b128 groups are bank-conflict free.  bf16 mode: v_mfma_f32_32x32x16_bf16; fp32 parity
+// mode: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  The accumulator tile goes through LDS once so that
+// global stores (and residual loads) are full 16-B-per-lane row segments.
+#include "common.h"
+#include "conv.h"
+
+namespace ivosw {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ROWB = 128;  // bytes per tile row per K-tile
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// WAVES_M x WAVES_N waves (4 total), each owning TM x TN 32x32 MFMA tiles.
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, bool STEM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int KE = ROWB / ES;   // elements per K-tile (64 bf16 / 32 fp32)
+    constexpr int CE = 16 / ES;     // elements per 16-B chunk
+    constexpr int AI = BM / 32, BI = BN / 32;  // rows per thread for the A / B staging passes
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int LDS_BYTES = (2 * STAGE_BYTES > EPI_BYTES) ? 2 * STAGE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nbn = p.Cout / BN;
+    const int nwg = gridDim.x;
+    const int L = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = L % nbn, tile_m = L / nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int M = p.B * p.Ho * p.Wo;
+
+    // ---- per-thread staging coordinates: chunk c of rows (tid>>3) + 32*i
+    const int c = tid & 7;
+    const int r0 = tid >> 3;
+    long abase[AI];
+    int aiy[AI], aix[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < M) {
+            const int b = m / (p.Ho * p.Wo);
+            const int rem = m - b * (p.Ho * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            aiy[i] = oy * p.stride - p.pad;
+            aix[i] = ox * p.stride - p.pad;
+            abase[i] = (long)b * p.H * p.W * p.Cin;
+        } else {
+            aiy[i] = -100000; aix[i] = -100000; abase[i] = 0;
+        }
+    }
+    const T* X = static_cast<const T*>(p.x);
+    const T* Wt = static_cast<const T*>(p.w);
+    const int K = STEM ? (ES == 2 ? 256 : 224) : p.KH * p.KW * p.Cin;
+    const int nk = K / KE;
+    const int ctiles = STEM ? 1 : p.Cin / KE;  // K-tiles per filter tap
+
+    uint4 ra[AI], rb[BI];
+    auto load_tiles = [&](int kt) {
+        if constexpr (!STEM) {
+            const int tap = kt / ctiles, c0 = (kt - tap * ctiles) * KE;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int iy = aiy[i] + ky, ix = aix[i] + kx;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    v = *reinterpret_cast<const uint4*>(X + abase[i] + ((long)iy * p.W + ix) * p.Cin + c0 + c * CE);
+                ra[i] = v;
+            }
+        } else {
+            // stem: Cin = 4 (R,G,B,P); one K-tile = filter row(s) of 8 pixels x 4 channels (8th pixel and, in
+            // bf16, the 8th filter row are zero-weight padding)
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if constexpr (ES == 2) {
+                    const int ky = 2 * kt + (c >> 2), px = (c & 3) * 2;
+                    const int iy = aiy[i] + ky, ix = aix[i] + px;
+                    if (ky < 7 && iy >= 0 && iy < p.H) {
+                        const T* row = X + abase[i] + (long)iy * p.W * 4;
+                        if (ix >= 0 && ix < p.W) { const uint2 t = *reinterpret_cast<const uint2*>(row + (long)ix * 4); v.x = t.x; v.y = t.y; }
+                        if (ix + 1 >= 0 && ix + 1 < p.W && px + 1 < 7) { const uint2 t = *reinterpret_cast<const uint2*>(row + (long)(ix + 1) * 4); v.z = t.x; v.w = t.y; }
+                    }
+                } else {
+                    const int iy = aiy[i] + kt, ix = aix[i] + c;
+                    if (c < 7 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                        v = *reinterpret_cast<const uint4*>(X + abase[i] + ((long)iy * p.W + ix) * 4);
+                }
+                ra[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            rb[i] = *reinterpret_cast<const uint4*>(Wt + (long)(n0 + r0 + 32 * i) * K + (long)kt * KE + c * CE);
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* As = lds + buf * STAGE_BYTES;
+        unsigned char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<uint4*>(As + swz(r0 + 32 * i, c)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<uint4*>(Bs + swz(r0 + 32 * i, c)) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const unsigned char* As = lds + buf * STAGE_BYTES;
+        const unsigned char* Bs = As + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            // 16-B chunk (2*ks + lhalf): bf16 -> k = 16*ks + 8*lhalf + [0,8) (one 32x32x16 MFMA);
+            // fp32 -> 4 floats feeding four 32x32x2 MFMAs (k-permutation identical for A and B)
+            const int ch = 2 * ks + lhalf;
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + swz((wm * TM + i) * 32 + lrow, ch));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + swz((wn * TN + j) * 32 + lrow, ch));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (ES == 2) {
+                        union { uint4 u; bf16x8 v; } ua, ub;
+                        ua.u = fa[i]; ub.u = fb[j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].x), __uint_as_float(fb[j].x), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].y), __uint_as_float(fb[j].y), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].z), __uint_as_float(fb[j].z), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i].w), __uint_as_float(fb[j].w), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue phase 1: accumulators -> LDS fp32 tile [BM][BN] (C/D map: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5))
+    float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const int col = (wn * TN + j) * 32 + lrow;
+                Cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    // ---- phase 2: 8 consecutive channels per thread: + bias (+ residual) -> ReLU -> 16/32-B stores
+    constexpr int CPR = BN / 8;  // 8-channel groups per row
+    T* Y = static_cast<T*>(p.y);
+    const T* R = static_cast<const T*>(p.res);
+#pragma unroll
+    for (int it = 0; it < (BM * CPR) / 256; ++it) {
+        const int item = it * 256 + tid;
+        const int row = item / CPR, cg = item - row * CPR;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        const int n = n0 + cg * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+        const long o = (long)m * p.Cout + n;
+        if constexpr (ES == 2) {
+            if (R) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(R + o);
+                const uint32_t w4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += bf16_to_f32((bf16_t)(w4[q] & 0xffff));
+                    v[2 * q + 1] += bf16_to_f32((bf16_t)(w4[q] >> 16));
+                }
+            }
+            uint32_t pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = v[2 * q], b = v[2 * q + 1];
+                if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                pk[q] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+            }
+            *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+            if (R) {
+                const float4 r0v = *reinterpret_cast<const float4*>(R + o);
+                const float4 r1v = *reinterpret_cast<const float4*>(R + o + 4);
+                v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
+                v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            *reinterpret_cast<float4*>(Y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(Y + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
+template <typename T, bool STEM>
+static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
+    const int M = a.B * a.Ho * a.Wo;
+    if (a.Cout % 128 == 0) {
+        const int grid = ((M + 127) / 128) * (a.Cout / 128);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 2, STEM>), dim3(grid), dim3(256), 0, st, a);
+    } else {  // Cout == 64 layers: 128 x 64 tile
+        const int grid = ((M + 127) / 128) * (a.Cout / 64);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 1, STEM>), dim3(grid), dim3(256), 0, st, a);
+    }
+}
+
+void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st) {
+    if (dtype == IVOSW_BF16) {
+        if (stem) launch_conv_t<bf16_t, true>(a, st); else launch_conv_t<bf16_t, false>(a, st);
+    } else {
+        if (stem) launch_conv_t<float, true>(a, st); else launch_conv_t<float, false>(a, st);
+    }
+}
+
+// ---------------------------------------------------------------- weight packing (BN fold + K-major repack)
+// w [Cout,Cin,KH,KW] fp32 -> out[Cout][(ky*KW+kx)*Cin + ci] * gamma/sqrt(var+eps); bias = beta - mean*scale
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int Cout, int Cin,
+                                 int KH, int KW, T* __restrict__ ow, float* __restrict__ ob) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long K = (long)KH * KW * Cin;
+    if (i >= (long)Cout * K) return;
+    const int co = (int)(i / K);
+    const int k = (int)(i - (long)co * K);
+    const int tap = k / Cin, ci = k - tap * Cin;
+    const int ky = tap / KW, kx = tap - ky * KW;
+    const float scale = gamma[co] / sqrtf(rvar[co] + eps);
+    ow[i] = Elem<T>::from_f32(w[(((long)co * Cin + ci) * KH + ky) * KW + kx] * scale);
+    if (k == 0) ob[co] = beta[co] - rmean[co] * scale;
+}
+
+// stem: conv1 [64,3,7,7] | conv1_p [64,1,7,7] -> out[64][KY][8 px][4 ch], zero for px == 7 / ky == 7
+template <typename T>
+__global__ void pack_stem_kernel(const float* __restrict__ w3, const float* __restrict__ w1, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                 float eps, int KY, T* __restrict__ ow, float* __restrict__ ob) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = KY * 32;
+    if (i >= 64 * K) return;
+    const int co = i / K, k = i - co * K;
+    const int ky = k >> 5, px = (k >> 2) & 7, ch = k & 3;
+    const float scale = gamma[co] / sqrtf(rvar[co] + eps);
+    float v = 0.f;
+    if (ky < 7 && px < 7) v = (ch < 3) ? w3[((co * 3 + ch) * 7 + ky) * 7 + px] : w1[(co * 7 + ky) * 7 + px];
+    ow[i] = Elem<T>::from_f32(v * scale);
+    if (k == 0) ob[co] = beta[co] - rmean[co] * scale;
+}
+
+void launch_pack_conv(const float* w, const float* g, const float* b, const float* rm, const float* rv, int Cout, int Cin,
+                      int KH, int KW, int dtype, void* ow, float* ob, hipStream_t st) {
+    const long n = (long)Cout * Cin * KH * KW;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == IVOSW_BF16)
+        hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, grid, dim3(256), 0, st, w, g, b, rm, rv, 1e-5f, Cout, Cin, KH, KW, static_cast<bf16_t*>(ow), ob);
+    else
+        hipLaunchKernelGGL(pack_conv_kernel<float>, grid, dim3(256), 0, st, w, g, b, rm, rv, 1e-5f, Cout, Cin, KH, KW, static_cast<float*>(ow), ob);
+}
+
+void launch_pack_stem(const float* w3, const float* w1, const float* g, const float* b, const float* rm, const float* rv,
+                      int dtype, void* ow, float* ob, hipStream_t st) {
+    const int KY = (dtype == IVOSW_BF16) ? 8 : 7;
+    const dim3 grid((64 * KY * 32 + 255) / 256);
+    if (dtype == IVOSW_BF16)
+        hipLaunchKernelGGL(pack_stem_kernel<bf16_t>, grid, dim3(256), 0, st, w3, w1, g, b, rm, rv, 1e-5f, KY, static_cast<bf16_t*>(ow), ob);
+    else
+        hipLaunchKernelGGL(pack_stem_kernel<float>, grid, dim3(256), 0, st, w3, w1, g, b, rm, rv, 1e-5f, KY, static_cast<float*>(ow), ob);
+}
+
+// ---------------------------------------------------------------- 3x3 stride-2 pad-1 max pool, NHWC (C = 64)
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, int B, int H, int W, int C, T* __restrict__ y) {
+    constexpr int CE = 16 / (int)sizeof(T);
+    const int Ho = H / 2, Wo = W / 2, CG = C / CE;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Ho * Wo * CG) return;
+    const int cg = (int)(i % CG);
+    long t = i / CG;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float m[CE];
+#pragma unroll
+    for (int q = 0; q < CE; ++q) m[q] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if (ix < 0 || ix >= W) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(x + (((long)b * H + iy) * W + ix) * C + cg * CE);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    m[2 * q] = fmaxf(m[2 * q], bf16_to_f32((bf16_t)(w4[q] & 0xffff)));
+                    m[2 * q + 1] = fmaxf(m[2 * q + 1], bf16_to_f32((bf16_t)(w4[q] >> 16)));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], __uint_as_float(w4[q]));
+            }
+        }
+    }
+    T* o = y + (((long)b * Ho + oy) * Wo + ox) * C + cg * CE;
+    if constexpr (sizeof(T) == 2) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = (uint32_t)f32_to_bf16(m[2 * q]) | ((uint32_t)f32_to_bf16(m[2 * q + 1]) << 16);
+        *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    } else {
+        *reinterpret_cast<float4*>(o) = make_float4(m[0], m[1], m[2], m[3]);
+    }
+}
+
+void launch_maxpool(const void* x, int B, int H, int W, int C, int dtype, void* y, hipStream_t st) {
+    if (dtype == IVOSW_BF16) {
+        const long n = (long)B * (H / 2) * (W / 2) * (C / 8);
+        hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const bf16_t*>(x), B, H, W, C, static_cast<bf16_t*>(y));
+    } else {
+        const long n = (long)B * (H / 2) * (W / 2) * (C / 4);
+        hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(x), B, H, W, C, static_cast<float*>(y));
+    }
+}
+
+// ---------------------------------------------------------------- 8x8 average pool + fc (2048 -> 1); one block per frame
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fc_kernel(const T* __restrict__ x, const float* __restrict__ fcw, const float* __restrict__ fcb,
+                                                      float* __restrict__ score, float* __restrict__ pooled_out) {
+    constexpr int C = 2048, P = 64;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = 0.f;
+    const T* base = x + (long)b * P * C + tid * 8;
+    for (int pidx = 0; pidx < P; ++pidx) {
+        if constexpr (sizeof(T) == 2) {
+            const uint4 v = *reinterpret_cast<const uint4*>(base + (long)pidx * C);
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[2 * q] += bf16_to_f32((bf16_t)(w4[q] & 0xffff));
+                s[2 * q + 1] += bf16_to_f32((bf16_t)(w4[q] >> 16));
+            }
+        } else {
+            const float4 v0 = *reinterpret_cast<const float4*>(base + (long)pidx * C);
+            const float4 v1 = *reinterpret_cast<const float4*>(base + (long)pidx * C + 4);
+            s[0] += v0.x; s[1] += v0.y; s[2] += v0.z; s[3] += v0.w;
+            s[4] += v1.x; s[5] += v1.y; s[6] += v1.z; s[7] += v1.w;
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float pv = s[q] * (1.0f / 64.0f);
+        if (pooled_out) pooled_out[(long)b * C + tid * 8 + q] = pv;
+        dot = fmaf(pv, fcw[tid * 8 + q], dot);
+    }
+    dot = wave_sum(dot);
+    __shared__ float red[4];
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) score[b] = (red[0] + red[1]) + (red[2] + red[3]) + fcb[0];
+}
+
+void launch_pool_fc(const void* x, int B, int dtype, const float* fcw, const float* fcb, float* score, float* pooled,
+                    hipStream_t st) {
+    if (dtype == IVOSW_BF16)
+        hipLaunchKernelGGL(pool_fc_kernel<bf16_t>, dim3(B), dim3(256), 0, st, static_cast<const bf16_t*>(x), fcw, fcb, score, pooled);
+    else
+        hipLaunchKernelGGL(pool_fc_kernel<float>, dim3(B), dim3(256), 0, st, static_cast<const float*>(x), fcw, fcb, score, pooled);
+}
+
+}  // namespace ivosw
