@@ -117,6 +117,13 @@ int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const f
 /* Name of the dominant kernel of the last ivosw_assess_forward configuration (for profiling).     */
 const char* ivosw_assess_dominant_kernel(int dtype);
 
+/* ------------------------------------------------------------------ measurement hooks ---------- */
+/* Not part of the reference surface: bench.py's roofline leg.  Between start and stop every launch of
+ * the dominant kernel family (conv_igemm_kernel) is bracketed by hipEvents on the launch stream; stop
+ * synchronises those events and returns the summed kernel time (ms) and the launch count.          */
+int ivosw_profile_start(void);
+int ivosw_profile_stop(double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,9 @@
 // 16-lane ds_read_b128 groups are bank-conflict free.  bf16 mode: v_mfma_f32_32x32x16_bf16; fp32 parity
 // mode: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  The accumulator tile goes through LDS once so that
 // global stores (and residual loads) are full 16-B-per-lane row segments.
+#include <utility>
+#include <vector>
+
 #include "common.h"
 #include "conv.h"
 
@@ -244,12 +247,34 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
     }
 }
 
+// measurement hook (include/ivosw.h: ivosw_profile_start/stop): hipEvent pairs around every conv launch
+struct ConvProfiler {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+};
+static ConvProfiler g_prof;
+
 void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_prof.on) {
+        if (g_prof.used == g_prof.ev.size()) {
+            hipEvent_t x, y;
+            (void)hipEventCreate(&x);
+            (void)hipEventCreate(&y);
+            g_prof.ev.emplace_back(x, y);
+        }
+        e0 = g_prof.ev[g_prof.used].first;
+        e1 = g_prof.ev[g_prof.used].second;
+        ++g_prof.used;
+        (void)hipEventRecord(e0, st);
+    }
     if (dtype == IVOSW_BF16) {
         if (stem) launch_conv_t<bf16_t, true>(a, st); else launch_conv_t<bf16_t, false>(a, st);
     } else {
         if (stem) launch_conv_t<float, true>(a, st); else launch_conv_t<float, false>(a, st);
     }
+    if (e1) (void)hipEventRecord(e1, st);
 }
 
 // ---------------------------------------------------------------- weight packing (BN fold + K-major repack)
@@ -414,3 +439,25 @@ void launch_pool_fc(const void* x, int B, int dtype, const float* fcw, const flo
 }
 
 }  // namespace ivosw
+
+extern "C" int ivosw_profile_start(void) {
+    ivosw::g_prof.on = true;
+    ivosw::g_prof.used = 0;
+    return IVOSW_OK;
+}
+
+extern "C" int ivosw_profile_stop(double* total_ms, int* launches) {
+    using namespace ivosw;
+    IVOSW_REQUIRE(total_ms && launches, "null pointer");
+    double tot = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        (void)hipEventSynchronize(g_prof.ev[i].second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i].first, g_prof.ev[i].second) == hipSuccess) tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int)g_prof.used;
+    g_prof.on = false;
+    g_prof.used = 0;
+    return IVOSW_OK;
+}
