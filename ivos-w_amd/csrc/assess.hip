@@ -4,6 +4,7 @@
 // Frames run through the whole tower in chunks (default 32 bf16 / 16 fp32) so that the layer-to-layer
 // activations of a chunk (<= ~2 MB per frame per tensor) stay resident in the 256 MiB Infinity Cache instead
 // of making a round trip to HBM between every pair of layers.
+#include <algorithm>
 #include <vector>
 
 #include "conv.h"
@@ -24,7 +25,7 @@ struct BlockPlan {
 struct Plan {
     std::vector<ConvPlan> convs;
     std::vector<BlockPlan> blocks;
-    size_t norm_off, fcw_off, fcb_off, stem_w_off, stem_b_off, total;
+    size_t norm_off, zero_off, fcw_off, fcb_off, stem_w_off, stem_b_off, total;
     int t_stem_w3, t_stem_w1, t_stem_bn, t_fcw, t_fcb, t_mean, t_std;
 };
 
@@ -34,6 +35,7 @@ static Plan make_plan(int dtype) {
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); const size_t o = off; off += bytes; return o; };
     P.norm_off = take(8 * sizeof(float));
+    P.zero_off = take(256);  // page of zeros: source of zero-padding taps for the LDS-DMA conv loader
     P.fcw_off = take(2048 * sizeof(float));
     P.fcb_off = take(sizeof(float));
     P.stem_w_off = take((size_t)64 * ((dtype == IVOSW_BF16) ? 256 : 224) * es);
@@ -81,29 +83,38 @@ __global__ void copy_small_kernel(const float* __restrict__ a, int na, const flo
     if (i < nb) o[na + i] = b[i];
 }
 
-// per-frame element counts of the activation buffers
-constexpr size_t E_ROI = 256 * 256 * 4, E_BIG = 64 * 64 * 256, E_MID = 64 * 64 * 128;
+// per-frame element counts
+constexpr size_t E_ROI = 256 * 256 * 4, E_BIG = 64 * 64 * 256;
+// per-frame output elements of res2..res5
+constexpr size_t E_OUT[4] = {64 * 64 * 256, 32 * 32 * 512, 16 * 16 * 1024, 8 * 8 * 2048};
 
+// Chunk schedule.  Stage s (res2..res5) runs on c0 * 2^s frames at a time: every stage halves H and W and
+// doubles C, so doubling the frames per launch keeps the per-stage working set constant (c0 * 2 MB bf16 per
+// tensor: Infinity-Cache resident) while every conv launch still has >= 512 workgroups for the 256 CUs.
 static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 32 : 16; }
 
 struct Bufs {
     float* yxhw; int32_t* box; float* pooled;
-    char *roi, *stem, *p0, *p1, *m1, *m2, *ds;
+    char *roi, *stem, *pa, *pb, *m1, *m2, *ds;
+    char* in[4];  // in[s]: input of stage s+1 = output of stage s, for the frames of the enclosing chunk (s = 0..2)
 };
 
-static size_t carve(Arena& ar, int dtype, int B, int chunk, Bufs* out) {
+static size_t carve(Arena& ar, int dtype, int B, int c0, Bufs* out) {
     const size_t es = (dtype == IVOSW_BF16) ? 2 : 4;
     Bufs b{};
+    const size_t c3 = (size_t)std::min(B, c0 * 8);
     b.yxhw = ar.take<float>((size_t)B * 4);
     b.box = ar.take<int32_t>((size_t)B * 4);
-    b.pooled = ar.take<float>((size_t)chunk * 2048);
-    b.roi = ar.take<char>(chunk * E_ROI * es);
-    b.stem = ar.take<char>(chunk * E_BIG * es);
-    b.p0 = ar.take<char>(chunk * E_BIG * es);
-    b.p1 = ar.take<char>(chunk * E_BIG * es);
-    b.ds = ar.take<char>(chunk * E_BIG * es);
-    b.m1 = ar.take<char>(chunk * E_MID * es);
-    b.m2 = ar.take<char>(chunk * E_MID * es);
+    b.pooled = ar.take<float>(c3 * 2048);
+    b.roi = ar.take<char>(c0 * E_ROI * es);
+    b.stem = ar.take<char>(c0 * E_BIG * es);
+    b.pa = ar.take<char>(c0 * E_BIG * es);
+    b.pb = ar.take<char>(c0 * E_BIG * es);
+    b.ds = ar.take<char>(c0 * E_BIG * es);
+    b.m1 = ar.take<char>(c0 * E_BIG * es);
+    b.m2 = ar.take<char>(c0 * E_BIG / 4 * es);
+    for (int s = 0; s < 3; ++s) b.in[s] = ar.take<char>((size_t)c0 * 2 * E_BIG * es);
+    b.in[3] = nullptr;
     if (out) *out = b;
     return align_up(ar.off, 256);
 }
@@ -127,6 +138,7 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
     char* base = static_cast<char*>(packed);
     auto T = [&](int i) { return static_cast<const float*>(tensors[i]); };
     for (int i : {P.t_mean, P.t_std, P.t_stem_w1, P.t_stem_w3, P.t_fcw, P.t_fcb}) IVOSW_REQUIRE(tensors[i], "null tensor");
+    (void)hipMemsetAsync(base + P.zero_off, 0, 256, st);
     hipLaunchKernelGGL(copy_small_kernel, dim3(1), dim3(64), 0, st, T(P.t_mean), 3, T(P.t_std), 3,
                        reinterpret_cast<float*>(base + P.norm_off));
     (void)hipMemcpyAsync(base + P.fcw_off, T(P.t_fcw), 2048 * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -187,56 +199,77 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
     RoiNorm nrm{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, reinterpret_cast<const float*>(base + P.norm_off)};
 
     const size_t plane = (size_t)H * W;
-    for (int f0 = 0; f0 < B; f0 += chunk) {
-        const int nb = (B - f0 < chunk) ? B - f0 : chunk;
-        // K3: ROI crop-resize + normalise -> NHWC4
-        launch_roi_sample(tf + (size_t)f0 * 3 * plane, tp + (size_t)f0 * plane, bf.yxhw + (size_t)f0 * 4, nb, H, W, dtype,
-                          nrm, bf.roi, st);
-        tap(1, bf.roi, nb * E_ROI * es);
-        // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool
-        ConvArgs a{};
-        a.x = bf.roi; a.w = base + P.stem_w_off; a.bias = reinterpret_cast<const float*>(base + P.stem_b_off);
-        a.res = nullptr; a.y = bf.stem; a.B = nb; a.H = 256; a.W = 256; a.Cin = 4; a.Ho = 128; a.Wo = 128; a.Cout = 64;
-        a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
-        launch_conv(a, dtype, true, st);
-        tap(2, bf.stem, (size_t)nb * 128 * 128 * 64 * es);
-        launch_maxpool(bf.stem, nb, 128, 128, 64, dtype, bf.p0, st);
-        tap(3, bf.p0, (size_t)nb * 64 * 64 * 64 * es);
-        // K5: 16 bottlenecks
-        char* x = bf.p0;
-        char* y = bf.p1;
-        int hw = 64;
-        int bi = 0;
-        const int nblk[4] = {3, 4, 6, 3};
-        for (int s = 0; s < 4; ++s) {
-            for (int b = 0; b < nblk[s]; ++b, ++bi) {
-                const BlockPlan& bp = P.blocks[bi];
-                const ConvPlan &c1 = P.convs[bp.c1], &c2 = P.convs[bp.c2], &c3 = P.convs[bp.c3];
-                const int ho = hw / c2.stride;
-                auto mk = [&](const ConvPlan& c, const void* in, int hin, int hout, const void* res, void* out, int relu) {
-                    ConvArgs q{};
-                    q.x = in; q.w = base + c.w_off; q.bias = reinterpret_cast<const float*>(base + c.b_off); q.res = res; q.y = out;
-                    q.B = nb; q.H = hin; q.W = hin; q.Cin = c.Cin; q.Ho = hout; q.Wo = hout; q.Cout = c.Cout;
-                    q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
-                    launch_conv(q, dtype, false, st);
-                };
-                mk(c1, x, hw, hw, nullptr, bf.m1, 1);
-                mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
-                const void* idt = x;
-                if (bp.ds >= 0) {
-                    mk(P.convs[bp.ds], x, hw, ho, nullptr, bf.ds, 0);
-                    idt = bf.ds;
-                }
-                mk(c3, bf.m2, ho, ho, idt, y, 1);  // relu(bn3(conv3) + identity)
-                char* t = x; x = y; y = t;
-                hw = ho;
+    const int nblk[4] = {3, 4, 6, 3}, first_blk[4] = {0, 3, 7, 13}, hw_in[4] = {64, 64, 32, 16};
+    const int cs[4] = {chunk, chunk * 2, chunk * 4, chunk * 8};
+
+    // one bottleneck stage (K5) on nb frames: x -> out (the last block writes straight into `out`)
+    auto run_stage = [&](int s, const char* x_in, int nb, char* out) {
+        const char* x = x_in;
+        int hw = hw_in[s];
+        for (int b = 0; b < nblk[s]; ++b) {
+            const BlockPlan& bp = P.blocks[first_blk[s] + b];
+            const ConvPlan &c1 = P.convs[bp.c1], &c2 = P.convs[bp.c2], &c3 = P.convs[bp.c3];
+            const int ho = hw / c2.stride;
+            char* y = (b == nblk[s] - 1) ? out : ((x == bf.pa) ? bf.pb : bf.pa);
+            auto mk = [&](const ConvPlan& c, const void* in, int hin, int hout, const void* res, void* o, int relu) {
+                ConvArgs q{};
+                q.zeros = base + P.zero_off; q.x = in; q.w = base + c.w_off; q.bias = reinterpret_cast<const float*>(base + c.b_off); q.res = res; q.y = o;
+                q.B = nb; q.H = hin; q.W = hin; q.Cin = c.Cin; q.Ho = hout; q.Wo = hout; q.Cout = c.Cout;
+                q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
+                launch_conv(q, dtype, false, st);
+            };
+            mk(c1, x, hw, hw, nullptr, bf.m1, 1);
+            mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
+            const void* idt = x;
+            if (bp.ds >= 0) {
+                mk(P.convs[bp.ds], x, hw, ho, nullptr, bf.ds, 0);
+                idt = bf.ds;
             }
-            tap(4 + s, x, (size_t)nb * hw * hw * P.convs[P.blocks[bi - 1].c3].Cout * es);
+            mk(c3, bf.m2, ho, ho, idt, y, 1);  // relu(bn3(conv3) + identity)
+            x = y;
+            hw = ho;
         }
+    };
+
+    for (int f3 = 0; f3 < B; f3 += cs[3]) {
+        const int n3 = std::min(cs[3], B - f3);
+        for (int f2 = f3; f2 < f3 + n3; f2 += cs[2]) {
+            const int n2 = std::min(cs[2], f3 + n3 - f2);
+            for (int f1 = f2; f1 < f2 + n2; f1 += cs[1]) {
+                const int n1 = std::min(cs[1], f2 + n2 - f1);
+                for (int f0 = f1; f0 < f1 + n1; f0 += cs[0]) {
+                    const int nb = std::min(cs[0], f1 + n1 - f0);
+                    // K3: ROI crop-resize + normalise -> NHWC4
+                    launch_roi_sample(tf + (size_t)f0 * 3 * plane, tp + (size_t)f0 * plane, bf.yxhw + (size_t)f0 * 4, nb, H, W,
+                                      dtype, nrm, bf.roi, st);
+                    tap(1, bf.roi, nb * E_ROI * es);
+                    // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool
+                    ConvArgs a{};
+                    a.zeros = base + P.zero_off; a.x = bf.roi; a.w = base + P.stem_w_off; a.bias = reinterpret_cast<const float*>(base + P.stem_b_off);
+                    a.res = nullptr; a.y = bf.stem; a.B = nb; a.H = 256; a.W = 256; a.Cin = 4; a.Ho = 128; a.Wo = 128;
+                    a.Cout = 64; a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
+                    launch_conv(a, dtype, true, st);
+                    tap(2, bf.stem, (size_t)nb * 128 * 128 * 64 * es);
+                    launch_maxpool(bf.stem, nb, 128, 128, 64, dtype, bf.pa, st);
+                    tap(3, bf.pa, (size_t)nb * 64 * 64 * 64 * es);
+                    char* o2 = bf.in[0] + (size_t)(f0 - f1) * E_OUT[0] * es;
+                    run_stage(0, bf.pa, nb, o2);
+                    tap(4, o2, nb * E_OUT[0] * es);
+                }
+                char* o3 = bf.in[1] + (size_t)(f1 - f2) * E_OUT[1] * es;
+                run_stage(1, bf.in[0], n1, o3);
+                tap(5, o3, n1 * E_OUT[1] * es);
+            }
+            char* o4 = bf.in[2] + (size_t)(f2 - f3) * E_OUT[2] * es;
+            run_stage(2, bf.in[1], n2, o4);
+            tap(6, o4, n2 * E_OUT[2] * es);
+        }
+        run_stage(3, bf.in[2], n3, bf.pa);  // c0*8 frames x 131k elements == c0 * E_BIG: fits a ping-pong buffer
+        tap(7, bf.pa, n3 * E_OUT[3] * es);
         // K6: 8x8 average pool + fc1
-        launch_pool_fc(x, nb, dtype, reinterpret_cast<const float*>(base + P.fcw_off),
-                       reinterpret_cast<const float*>(base + P.fcb_off), scores + f0, tap_stage == 8 ? bf.pooled : nullptr, st);
-        tap(8, bf.pooled, (size_t)nb * 2048 * sizeof(float));
+        launch_pool_fc(bf.pa, n3, dtype, reinterpret_cast<const float*>(base + P.fcw_off),
+                       reinterpret_cast<const float*>(base + P.fcb_off), scores + f3, tap_stage == 8 ? bf.pooled : nullptr, st);
+        tap(8, bf.pooled, (size_t)n3 * 2048 * sizeof(float));
     }
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;

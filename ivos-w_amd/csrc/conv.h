@@ -10,6 +10,7 @@ struct ConvArgs {
     const float* bias;  // [Cout] folded BN shift
     const void* res;    // NHWC [B,Ho,Wo,Cout] residual added before the ReLU, or nullptr
     void* y;            // NHWC [B,Ho,Wo,Cout]
+    const void* zeros;  // >= 16 B of device zeros: source of the zero-padding taps for the LDS-DMA loader
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
 };
 

@@ -28,6 +28,61 @@ constexpr int ROWB = 128;  // bytes per tile row per K-tile
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// epilogue phase 2: 8 consecutive channels per thread: + bias (+ residual) -> ReLU -> 16/32-B stores
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* Cs, int m0, int n0, int M, int tid) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CPR = BN / 8;  // 8-channel groups per row
+    T* Y = static_cast<T*>(p.y);
+    const T* R = static_cast<const T*>(p.res);
+#pragma unroll
+    for (int it = 0; it < (BM * CPR) / 256; ++it) {
+        const int item = it * 256 + tid;
+        const int row = item / CPR, cg = item - row * CPR;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        const int n = n0 + cg * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+        const long o = (long)m * p.Cout + n;
+        if constexpr (ES == 2) {
+            if (R) {
+                const uint4 rr = *reinterpret_cast<const uint4*>(R + o);
+                const uint32_t w4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += bf16_to_f32((bf16_t)(w4[q] & 0xffff));
+                    v[2 * q + 1] += bf16_to_f32((bf16_t)(w4[q] >> 16));
+                }
+            }
+            uint32_t pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = v[2 * q], b = v[2 * q + 1];
+                if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                pk[q] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+            }
+            *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+            if (R) {
+                const float4 r0v = *reinterpret_cast<const float4*>(R + o);
+                const float4 r1v = *reinterpret_cast<const float4*>(R + o + 4);
+                v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
+                v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            *reinterpret_cast<float4*>(Y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(Y + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
 // WAVES_M x WAVES_N waves (4 total), each owning TM x TN 32x32 MFMA tiles.
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, bool STEM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
@@ -183,67 +238,203 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
                 Cs[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
-    // ---- phase 2: 8 consecutive channels per thread: + bias (+ residual) -> ReLU -> 16/32-B stores
-    constexpr int CPR = BN / 8;  // 8-channel groups per row
-    T* Y = static_cast<T*>(p.y);
-    const T* R = static_cast<const T*>(p.res);
+    epilogue_store<T, BM, BN>(p, Cs, m0, n0, M, tid);
+}
+
+// ---------------------------------------------------------------- LDS-DMA pipelined variant (tower convs)
+// Same GEMM view and LDS image as above, but tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per
+// wave-instruction, no VGPR round trip) into an S-deep ring, with counted s_waitcnt vmcnt(N) and ONE raw
+// s_barrier per K-tile, so S-1 tiles (up to 96 KB per CU) stay in flight under the MFMAs.  The DMA writes LDS
+// lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied on the SOURCE side: the lane that
+// lands on chunk position p of row r fetches chunk p ^ ((r>>1)&7); reads use the same involution.  Zero padding:
+// out-of-image taps fetch from a 16-B page of zeros.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// Fragment reads are inline asm: hipcc cannot prove a ds_read does not alias the in-flight LDS-DMA of another
+// ring slot and would drain the whole pipeline (s_waitcnt vmcnt(0)) in front of every K-step.  Reads issued this
+// way are not tracked by the compiler: lds_wait() (lgkmcnt(0) + scheduling fence) must precede their first use.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs p) {
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int KE = ROWB / ES, CE = 16 / ES;
+    constexpr int AG = BM / 32, BG = BN / 32;  // 8-row groups (= DMA instructions) per wave per K-tile
+    constexpr int LPT = AG + BG;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int LDS_BYTES = (S * STAGE_BYTES > EPI_BYTES) ? S * STAGE_BYTES : EPI_BYTES;
+    static_assert(S >= 2 && S <= 4, "ring depth");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];  // the ONLY LDS object (keeps hipcc from draining vmcnt)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nbn = p.Cout / BN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = L % nbn, tile_m = L / nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int M = p.B * p.Ho * p.Wo;
+
+    const T* X = static_cast<const T*>(p.x);
+    const T* Wt = static_cast<const T*>(p.w);
+    const int K = p.KH * p.KW * p.Cin;
+    const int nk = K / KE;
+    const int ctiles = p.Cin / KE;
+
+    // ---- this lane's DMA duty: row (l>>3) of each of the wave's 8-row groups, chunk position (l&7)
+    const int rsub = lane >> 3, cpos = lane & 7;
+    long abase[AG];
+    int aiy[AG], aix[AG], achunk[AG];
 #pragma unroll
-    for (int it = 0; it < (BM * CPR) / 256; ++it) {
-        const int item = it * 256 + tid;
-        const int row = item / CPR, cg = item - row * CPR;
+    for (int i = 0; i < AG; ++i) {
+        const int row = (wave * AG + i) * 8 + rsub;
+        achunk[i] = (cpos ^ ((row >> 1) & 7)) * CE;
         const int m = m0 + row;
-        if (m >= M) continue;
-        const int n = n0 + cg * 8;
-        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
-        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-        float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
-        const long o = (long)m * p.Cout + n;
-        if constexpr (ES == 2) {
-            if (R) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(R + o);
-                const uint32_t w4[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[2 * q] += bf16_to_f32((bf16_t)(w4[q] & 0xffff));
-                    v[2 * q + 1] += bf16_to_f32((bf16_t)(w4[q] >> 16));
-                }
-            }
-            uint32_t pk[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float a = v[2 * q], b = v[2 * q + 1];
-                if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-                pk[q] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-            }
-            *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        if (m < M) {
+            const int b = m / (p.Ho * p.Wo);
+            const int rem = m - b * (p.Ho * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            aiy[i] = oy * p.stride - p.pad;
+            aix[i] = ox * p.stride - p.pad;
+            abase[i] = (long)b * p.H * p.W * p.Cin;
         } else {
-            if (R) {
-                const float4 r0v = *reinterpret_cast<const float4*>(R + o);
-                const float4 r1v = *reinterpret_cast<const float4*>(R + o + 4);
-                v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
-                v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
-            }
-            *reinterpret_cast<float4*>(Y + o) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(Y + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            aiy[i] = -100000; aix[i] = -100000; abase[i] = 0;
         }
     }
+    const T* bsrc[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave * BG + i) * 8 + rsub;
+        bsrc[i] = Wt + (long)(n0 + row) * K + (cpos ^ ((row >> 1) & 7)) * CE;
+    }
+    const T* zeros = static_cast<const T*>(p.zeros);
+
+    auto issue = [&](int kt, int stage) {
+        const int tap = kt / ctiles, c0 = (kt - tap * ctiles) * KE;
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        unsigned char* sb = lds + stage * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            const int iy = aiy[i] + ky, ix = aix[i] + kx;
+            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const T* src = ok ? X + abase[i] + ((long)iy * p.W + ix) * p.Cin + c0 + achunk[i] : zeros;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (wave * AG + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BG; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + (long)kt * KE), (lptr_t)(sb + BM * ROWB + (wave * BG + i) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int stage = 0;            // ring slot of tile kt
+    int fill = S - 1;         // ring slot the next issued tile goes to
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles kt+1 .. kt+ahead were issued after tile kt and may stay in flight
+        const int ahead = min(S - 2, nk - 1 - kt);
+        if (ahead >= 2) wait_vmcnt<2 * LPT>();
+        else if (ahead == 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // every wave's share of tile kt has landed; every wave is done with tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + S - 1 < nk) issue(kt + S - 1, fill);   // refill the slot tile kt-1 just vacated
+        const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
+        u32x4 fa[2][TM], fb[2][TN];
+        auto frag_read = [&](int ks, int buf) {
+            const int ch = 2 * ks + lhalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, ch));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[buf][j] = lds_read_b128(b_base + swz((wn * TN + j) * 32 + lrow, ch));
+        };
+        frag_read(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            lds_wait();                                  // fragments of K-step ks are in registers
+            if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);  // next K-step's reads fly under this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const u32x4 av = fa[ks & 1][i], bv = fb[ks & 1][j];
+                    if constexpr (ES == 2) {
+                        union { u32x4 u; bf16x8 v; } ua, ub;
+                        ua.u = av; ub.u = bv;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.x), __uint_as_float(bv.x), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.y), __uint_as_float(bv.y), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.z), __uint_as_float(bv.z), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.w), __uint_as_float(bv.w), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        stage = (stage + 1 == S) ? 0 : stage + 1;
+        fill = (fill + 1 == S) ? 0 : fill + 1;
+    }
+    __syncthreads();  // nothing in flight (last wait was vmcnt(0)); all waves done reading the ring
+
+    // ---- epilogue: identical to the register-staged kernel
+    float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const int col = (wn * TN + j) * 32 + lrow;
+                Cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    epilogue_store<T, BM, BN>(p, Cs, m0, n0, M, tid);
 }
 
 template <typename T, bool STEM>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
     const int M = a.B * a.Ho * a.Wo;
-    if (a.Cout % 128 == 0) {
-        const int grid = ((M + 127) / 128) * (a.Cout / 128);
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 2, STEM>), dim3(grid), dim3(256), 0, st, a);
-    } else {  // Cout == 64 layers: 128 x 64 tile
+    if constexpr (STEM) {
         const int grid = ((M + 127) / 128) * (a.Cout / 64);
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 1, STEM>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 1, true>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        // ring depth by K-loop length: short loops (1x1 convs on 64/128 channels) keep 2 workgroups per CU
+        const int nk = a.KH * a.KW * a.Cin / (128 / (int)sizeof(T));
+        if (a.Cout % 128 == 0) {
+            const int grid = ((M + 127) / 128) * (a.Cout / 128);
+            if (nk >= 3) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 2, 4>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 2, 2>), dim3(grid), dim3(256), 0, st, a);
+        } else {  // Cout == 64 layers: 128 x 64 tile
+            const int grid = ((M + 127) / 128) * (a.Cout / 64);
+            if (nk >= 3) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 1, 4>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 1, 2>), dim3(grid), dim3(256), 0, st, a);
+        }
     }
 }
 

@@ -1,0 +1,43 @@
+"""Summarise a rocprofv3 rocpd sqlite database (kernel-trace) as text: per-kernel totals and, for one
+kernel family, a per-launch-shape breakdown.  usage: rocprof_summary.py results.db [family-substring]"""
+import sqlite3
+import subprocess
+import sys
+
+
+def demangle(n):
+    n = n[:-3] if n.endswith(".kd") else n
+    try:
+        return subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip() or n
+    except Exception:
+        return n
+
+
+def main():
+    db, fam = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "conv_igemm_kernel")
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute(
+        "select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
+        "max(s.arch_vgpr_count), max(s.accum_vgpr_count), max(s.sgpr_count), max(d.group_segment_size) "
+        "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+        "group by s.kernel_name order by 3 desc"))
+    total = sum(r[2] for r in rows)
+    print(f"# rocprofv3 --kernel-trace summary of {db}\n# total kernel time {total/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches\n")
+    print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'pct':>6} {'vgpr':>5} {'agpr':>5} {'sgpr':>5} {'lds':>7}  kernel")
+    for r in rows:
+        print(f"{r[1]:7d} {r[2]/1e6:10.3f} {r[3]/1e3:9.2f} {r[4]/1e3:9.2f} {r[5]/1e3:9.2f} {100*r[2]/total:6.2f} {r[6]:5d} {r[7]:5d} {r[8]:5d} {r[9]:7d}  {demangle(r[0])[:150]}")
+    print(f"\n# launches of *{fam}* by (instance, grid): one line per distinct layer shape class")
+    rows = list(cur.execute(
+        "select s.kernel_name, d.grid_size_x, count(*), sum(d.end-d.start), avg(d.end-d.start) "
+        "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+        f"where s.kernel_name like '%{fam}%' group by s.kernel_name, d.grid_size_x order by 4 desc"))
+    ft = sum(r[3] for r in rows)
+    n = sum(r[2] for r in rows)
+    print(f"# family total {ft/1e6:.3f} ms, {n} launches, avg {ft/max(n,1)/1e3:.2f} us\n")
+    print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>9} {'pct':>6} {'blocks':>8}  instance")
+    for r in rows:
+        print(f"{r[2]:7d} {r[3]/1e6:10.3f} {r[4]/1e3:9.2f} {100*r[3]/ft:6.2f} {r[1]//256:8d}  {demangle(r[0])[:120]}")
+
+
+if __name__ == "__main__":
+    main()
