@@ -117,6 +117,12 @@ def bench_assess(args, rank, world, dev, dist):
     lib.ivosw_profile_start()
     for _ in range(psteps):
         step()
+    if args.layer_report and rank == 0:
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.ivosw_profile_report(buf, len(buf))
+        with open(args.layer_report, "w") as f:
+            f.write(f"# per-layer conv timing (HIP events, {psteps} steps, batch {args.batch}, chunk {args.chunk or 'default'}, {args.precision})\n")
+            f.write(buf.value.decode())
     tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
     lib.ivosw_profile_stop(ctypes.byref(tot), ctypes.byref(cnt))
     conv_ms = tot.value / psteps
@@ -208,6 +214,7 @@ def main():
     ap.add_argument("--replay", type=int, default=50000)
     ap.add_argument("--dqn-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-report", default="", help="write a per-conv-layer timing table (HIP events) to this file")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")

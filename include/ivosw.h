@@ -123,6 +123,9 @@ const char* ivosw_assess_dominant_kernel(int dtype);
  * synchronises those events and returns the summed kernel time (ms) and the launch count.          */
 int ivosw_profile_start(void);
 int ivosw_profile_stop(double* total_ms, int* launches);
+/* Text table (one line per distinct conv layer shape: calls, avg us, TFLOP/s, GB/s) of the launches recorded
+ * since ivosw_profile_start; call before ivosw_profile_stop.  buf is a HOST buffer of `cap` bytes.       */
+int ivosw_profile_report(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ivosw_assess_dominant_kernel": (C.c_char_p, [_i]),
     "ivosw_profile_start": (_i, []),
     "ivosw_profile_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
+    "ivosw_profile_report": (_i, [C.c_char_p, _sz]),
 }
 
 _lib = None

@@ -29,15 +29,15 @@ constexpr int ROWB = 128;  // bytes per tile row per K-tile
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // epilogue phase 2: 8 consecutive channels per thread: + bias (+ residual) -> ReLU -> 16/32-B stores
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NT = 256>
 __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* Cs, int m0, int n0, int M, int tid) {
     constexpr int ES = (int)sizeof(T);
     constexpr int CPR = BN / 8;  // 8-channel groups per row
     T* Y = static_cast<T*>(p.y);
     const T* R = static_cast<const T*>(p.res);
 #pragma unroll
-    for (int it = 0; it < (BM * CPR) / 256; ++it) {
-        const int item = it * 256 + tid;
+    for (int it = 0; it < (BM * CPR) / NT; ++it) {
+        const int item = it * NT + tid;
         const int row = item / CPR, cg = item - row * CPR;
         const int m = m0 + row;
         if (m >= M) continue;
@@ -269,11 +269,13 @@ __device__ __forceinline__ void lds_wait() {
 }
 
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(ConvArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int ES = (int)sizeof(T);
     constexpr int KE = ROWB / ES, CE = 16 / ES;
-    constexpr int AG = BM / 32, BG = BN / 32;  // 8-row groups (= DMA instructions) per wave per K-tile
+    constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW;  // 8-row groups (= DMA instructions) per wave per K-tile
+    static_assert(AG * 8 * NW == BM && BG * 8 * NW == BN, "tile rows must split evenly over the waves");
     constexpr int LPT = AG + BG;
     constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int EPI_BYTES = BM * BN * 4;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(ConvArgs p) {
                 Cs[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
-    epilogue_store<T, BM, BN>(p, Cs, m0, n0, M, tid);
+    epilogue_store<T, BM, BN, NW * 64>(p, Cs, m0, n0, M, tid);
 }
 
 template <typename T, bool STEM>
@@ -424,16 +426,18 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
         const int grid = ((M + 127) / 128) * (a.Cout / 64);
         hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 1, true>), dim3(grid), dim3(256), 0, st, a);
     } else {
-        // ring depth by K-loop length: short loops (1x1 convs on 64/128 channels) keep 2 workgroups per CU
+        // Tile / ring selection.  8 waves (2 per SIMD) so one wave's LDS-DMA issue overlaps the other's MFMAs;
+        // 256-row tiles halve the DMA instructions per MFMA.  Short K loops (1x1 convs on 64/128 channels) use a
+        // 2-deep ring.
         const int nk = a.KH * a.KW * a.Cin / (128 / (int)sizeof(T));
         if (a.Cout % 128 == 0) {
-            const int grid = ((M + 127) / 128) * (a.Cout / 128);
-            if (nk >= 3) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 2, 4>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 2, 2>), dim3(grid), dim3(256), 0, st, a);
-        } else {  // Cout == 64 layers: 128 x 64 tile
-            const int grid = ((M + 127) / 128) * (a.Cout / 64);
-            if (nk >= 3) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 1, 4>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 2, 2, 2, 1, 2>), dim3(grid), dim3(256), 0, st, a);
+            const int grid = ((M + 255) / 256) * (a.Cout / 128);
+            if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 2>), dim3(grid), dim3(512), 0, st, a);
+        } else {  // Cout == 64 layers: 256 x 64 tile
+            const int grid = ((M + 255) / 256) * (a.Cout / 64);
+            if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 3>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 2>), dim3(grid), dim3(512), 0, st, a);
         }
     }
 }
@@ -442,6 +446,8 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
 struct ConvProfiler {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<ConvArgs> args;
+    std::vector<int> es;
     size_t used = 0;
 };
 static ConvProfiler g_prof;
@@ -457,6 +463,9 @@ void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st) {
         }
         e0 = g_prof.ev[g_prof.used].first;
         e1 = g_prof.ev[g_prof.used].second;
+        if (g_prof.args.size() <= g_prof.used) { g_prof.args.resize(g_prof.used + 1); g_prof.es.resize(g_prof.used + 1); }
+        g_prof.args[g_prof.used] = a;
+        g_prof.es[g_prof.used] = (dtype == IVOSW_BF16) ? 2 : 4;
         ++g_prof.used;
         (void)hipEventRecord(e0, st);
     }
@@ -634,6 +643,39 @@ void launch_pool_fc(const void* x, int B, int dtype, const float* fcw, const flo
 extern "C" int ivosw_profile_start(void) {
     ivosw::g_prof.on = true;
     ivosw::g_prof.used = 0;
+    return IVOSW_OK;
+}
+
+// per-layer-shape table of the launches recorded since ivosw_profile_start (call before ivosw_profile_stop)
+extern "C" int ivosw_profile_report(char* buf, size_t cap) {
+    using namespace ivosw;
+    IVOSW_REQUIRE(buf && cap > 0, "null buffer");
+    struct Row { ConvArgs a; int es; int n; double ms; };
+    std::vector<Row> rows;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        (void)hipEventSynchronize(g_prof.ev[i].second);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, g_prof.ev[i].first, g_prof.ev[i].second);
+        const ConvArgs& a = g_prof.args[i];
+        bool found = false;
+        for (Row& r : rows)
+            if (r.a.B == a.B && r.a.H == a.H && r.a.Cin == a.Cin && r.a.Cout == a.Cout && r.a.KH == a.KH && r.a.stride == a.stride &&
+                (r.a.res != nullptr) == (a.res != nullptr)) { r.n++; r.ms += ms; found = true; break; }
+        if (!found) rows.push_back(Row{a, g_prof.es[i], 1, ms});
+    }
+    size_t off = 0;
+    off += snprintf(buf + off, cap - off, "%5s %4s %5s %5s %2s %2s %3s %5s %9s %9s %8s %8s\n", "B", "H", "Cin", "Cout", "K", "s", "res", "calls",
+                    "avg_us", "total_ms", "TFLOP/s", "GB/s");
+    for (const Row& r : rows) {
+        if (off + 160 > cap) break;
+        const ConvArgs& a = r.a;
+        const double M = (double)a.B * a.Ho * a.Wo;
+        const double flops = 2.0 * M * a.Cout * a.KH * a.KW * a.Cin;
+        const double bytes = ((double)a.B * a.H * a.W * a.Cin + M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * a.KH * a.KW * a.Cin) * r.es;
+        const double t = r.ms / r.n * 1e-3;
+        off += snprintf(buf + off, cap - off, "%5d %4d %5d %5d %2d %2d %3d %5d %9.2f %9.3f %8.1f %8.1f\n", a.B, a.H, a.Cin, a.Cout, a.KH, a.stride,
+                        a.res ? 1 : 0, r.n, r.ms / r.n * 1e3, r.ms, flops / t / 1e12, bytes / t / 1e9);
+    }
     return IVOSW_OK;
 }
 
