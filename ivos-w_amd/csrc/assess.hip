@@ -164,7 +164,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
     (void)dtype;
-    return "conv_igemm_kernel";
+    return "conv_igemm";
 }
 
 extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp, int B, int H, int W,

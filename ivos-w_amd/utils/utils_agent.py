@@ -1,0 +1,155 @@
+"""Recommendation glue around the hot path — drop-in for the reference's ``utils.utils_agent``.
+
+Function names, argument meaning and return values follow /root/reference/utils/utils_agent.py
+(``goal_only_reward`` :7-35, ``select_next_frame`` :38-74, ``recommend_frame`` :77-128, ``gen_subseq`` :131-157,
+``agent_train_data_collection`` :160-204, ``agent_business`` :207-256).  What changed is where the data lives:
+in the wild/ours and wild/worst branches the whole video stays on the GPU, all objects of a sequence are scored by
+ONE batched AssessNet launch (the reference runs one forward per object and copies the video H2D every
+interaction, :114-119), and the scores come back as one small D2H copy.
+"""
+import copy
+
+import numpy as np
+import torch
+
+
+def goal_only_reward(sequence, n_interaction, scribble_iter, repeat_selection, iou_new, df=None):
+    """reward_step = +1 / -1 (repeat selection); reward_done = (mean(J&F) - mu - sigma) / sigma against the 30
+    random-policy baselines stored in reward.csv (ddof=1)."""
+    reward_step = np.array(-1) if repeat_selection else np.array(1)
+    if df is None:
+        return reward_step, np.array(0)
+    rows = df[(df.sequence == sequence) & (df.n_interaction_next == n_interaction)]
+    rows = rows[((rows.scribble_iter - 1) % 3) == ((scribble_iter - 1) % 3)]
+    baseline = np.array([np.mean([float(tok) for tok in s.split("/")]) for s in rows.next_state_iou])
+    assert len(baseline) == 30
+    mu, sigma = baseline.mean(), baseline.std(ddof=1)
+    return reward_step, (iou_new.mean() - mu - sigma) / sigma
+
+
+def select_next_frame(frame_value, metric="min", prev_frames=None):
+    """'random' | 'worst'/'min' (lowest value not yet annotated) | 'max' (negates, like the reference) | 'prob'."""
+    n = len(frame_value)
+    if metric == "random":
+        return int(np.random.randint(n, size=1)[0])
+    if metric == "uniform":
+        assert prev_frames is not None
+    if metric == "prob":
+        draw = np.random.rand()
+        prob = torch.softmax(torch.Tensor(frame_value), 0)
+        k = 0
+        while draw > 0:
+            draw = draw - prob[k]
+            k += 1
+        return k - 1
+    if metric == "max":
+        frame_value = -frame_value
+    if prev_frames is None:
+        return frame_value.argmin()
+    for idx in frame_value.argsort():
+        if idx not in prev_frames:
+            return idx
+    return frame_value.argmin()          # every frame already annotated
+
+
+def gen_subseq(first_frame, n_frame, len_subseq, subseq_style="consecutive"):
+    if subseq_style == "consecutive":
+        assert n_frame >= len_subseq
+        lo = max(0, first_frame - len_subseq + 1)
+        hi = first_frame - max(first_frame + len_subseq - n_frame, 0)
+        start = int((lo + hi) / 2)
+        return list(range(start, start + len_subseq))
+    if subseq_style == "equal":
+        if n_frame < len_subseq + 1:
+            return list(np.array(range(len_subseq)))
+        grid = np.linspace(0, n_frame - 1, num=len_subseq + 1).astype(int)
+        while first_frame not in list(grid):
+            grid += 1
+        return list(grid[:-1]) if first_frame != grid[-1] else list(grid[1:])
+    raise NotImplementedError
+
+
+def _annotation_counts(n, annotated_frames_list):
+    counts = np.zeros(n)
+    for i in annotated_frames_list:
+        counts[i] += 1
+    return counts
+
+
+def assess_all_objects(assess_net, all_F, all_P, n_objects, device):
+    """[n_frame, n_objects] quality predictions from one batched launch: frames are repeated per object on the
+    device (the assessment kernels only read them) and channel i+1 of all_P is object i's soft mask."""
+    all_F = all_F.to(device)
+    all_P = all_P.to(device)
+    n = all_F.shape[0]
+    frames = all_F.repeat(n_objects, 1, 1, 1) if n_objects > 1 else all_F
+    masks = all_P[:, 1:n_objects + 1].transpose(0, 1).reshape(n_objects * n, *all_P.shape[2:]).contiguous()
+    scores = assess_net(frames, masks).reshape(n_objects, n)
+    return scores.transpose(0, 1).cpu().numpy()
+
+
+def recommend_frame(cfg_yl, assess_net, agent, device, n_frame, n_objects, all_F, all_P, new_masks_quality, prev_frames,
+                    annotated_frames_list, mask_quality, first_frame, max_nb_interactions):
+    setting, method = cfg_yl.setting, cfg_yl.method
+    if setting == "oracle":
+        if method == "worst":
+            return select_next_frame(new_masks_quality, metric="worst", prev_frames=prev_frames)
+        if method == "ours":
+            state = np.stack([new_masks_quality, _annotation_counts(len(new_masks_quality), annotated_frames_list)], 1)
+            with torch.no_grad():
+                return agent.action(state)
+        raise NotImplementedError
+    if setting == "wild":
+        if method == "random":
+            return select_next_frame(new_masks_quality, metric="random")
+        if method == "linspace":
+            subseq = gen_subseq(first_frame, n_frame, min(max_nb_interactions, n_frame), "equal")
+            return next((i for i in subseq if i not in prev_frames), prev_frames[0])
+        if method in ("worst", "ours"):
+            with torch.no_grad():
+                pred = assess_all_objects(assess_net, all_F, all_P, n_objects, device)
+            mask_quality[:] = pred.mean(1)          # in place: the caller logs corr/diff from this array
+            if method == "worst":
+                return select_next_frame(mask_quality, metric="worst", prev_frames=prev_frames)
+            state = np.stack([mask_quality, _annotation_counts(len(new_masks_quality), annotated_frames_list)], 1)
+            with torch.no_grad():
+                return agent.action(state)
+        raise NotImplementedError
+    raise NotImplementedError
+
+
+def agent_train_data_collection(agent, reward_step, reward_done, annotated_frames_list_np, next_annotated_frames_list_np,
+                                old_masks_IoU, new_masks_IoU, old_masks_meta, new_masks_meta, done, old_frame,
+                                report_save_dir):
+    """Serialise the per-frame vectors as '/'-joined str(float) lists (the memory_pool.csv cell format) and push."""
+    join = lambda seq: "/".join(str(v) for v in seq)
+    n = len(old_masks_IoU)
+    agent.memory(old_masks_meta, old_frame, new_masks_meta, reward_step, reward_done, done,
+                 join(old_masks_IoU[i] for i in range(n)), join(new_masks_IoU[i] for i in range(n)),
+                 join(annotated_frames_list_np[i] for i in range(n)),
+                 join(next_annotated_frames_list_np[i] for i in range(n)), report_save_dir)
+
+
+def agent_business(cfg_yl, agent, max_nb_interactions, n_interaction, first_scribble, old_masks_metric, new_masks_metric,
+                   old_frame, sequence, seen_seq, repeat_selection, df, annotated_frames_list, next_frame, old_masks_meta,
+                   new_masks_meta, report_save_dir, agent_train_loader):
+    agent_loss_iter, reward_step, reward_done = np.array(0), np.array(0), np.array(0)
+    if first_scribble or cfg_yl.phase == "eval":
+        return agent_loss_iter, reward_step, reward_done
+    reward_step, reward_done = goal_only_reward(sequence, n_interaction, seen_seq[sequence], repeat_selection,
+                                                new_masks_metric, df=df)
+    n = len(new_masks_metric)
+    nxt = copy.deepcopy(annotated_frames_list)
+    nxt.append(next_frame)
+    done = n_interaction >= max_nb_interactions
+    agent_train_data_collection(agent, reward_step, reward_done, _annotation_counts(n, annotated_frames_list),
+                                _annotation_counts(n, nxt), old_masks_metric, new_masks_metric, old_masks_meta,
+                                new_masks_meta, done, old_frame, report_save_dir)
+    if n_interaction == max_nb_interactions and cfg_yl.phase == "train":
+        losses = []
+        for i, sample in enumerate(agent_train_loader):
+            if i == max_nb_interactions * 3 - 1:          # at most 3*max_nb_interactions - 1 DQN steps per episode
+                break
+            losses.append(agent.update_agent(sample))
+        agent_loss_iter = np.array(losses).mean()
+    return agent_loss_iter, reward_step, reward_done

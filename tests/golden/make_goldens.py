@@ -222,6 +222,128 @@ def make_assess():
     print("assess_forward.npz", sum(v.nbytes for v in out.values()), "bytes")
 
 
+
+# ----------------------------------------------------------------------------- replay memory / sampler
+def fixture_rows(n=9, T=4, seed=3):
+    """Deterministic transitions in the reference's CSV cell format ('/'-joined str(float))."""
+    rs = np.random.RandomState(seed)
+    seqs = ["bear", "camel", "drift", "bear", "camel", "elephant", "drift", "bear", "flamingo"]
+    rows = []
+    for i in range(n):
+        iou = np.round(rs.uniform(0.5, 0.8, T), 4)
+        if seqs[i] == "camel":                                # camel never improves by > 0.05: filtered by sample_th
+            iou = np.full(T, 0.3)
+        gain = 0.01 if seqs[i] == "camel" else 0.1
+        nxt = np.round(np.clip(iou + gain, 0, 1), 4)
+        ann = np.zeros(T)
+        ann[rs.randint(T)] += 1
+        act = int(rs.randint(T))
+        nann = ann.copy()
+        nann[act] += 1
+        j = lambda a: "/".join(str(float(v)) for v in a)
+        rows.append(dict(sequence=seqs[i], scribble_iter=1 + i % 3, n_interaction=1 + i % 4, n_interaction_next=2 + i % 4,
+                         action=act, reward_step=1 if i % 3 else -1, reward_done=float(np.round(rs.randn(), 5)),
+                         done=bool(i % 4 == 3), state_iou=j(iou), next_state_iou=j(nxt), annotated_frames=j(ann),
+                         next_annotated_frames=j(nann)))
+    return rows
+
+
+def make_replay():
+    import shutil
+    import tempfile
+    from models.momory_pool import ReplayMemory
+    from datasets.agent_dataset import DAVIS2017AgentTrain
+    out = {}
+    rows = fixture_rows()
+    tmp = tempfile.mkdtemp(prefix="ivosw_gold_")
+    try:
+        # (1) push / push_to_csv with capacity 5 (ring wraps, oldest CSV rows dropped)
+        mem = ReplayMemory(5)
+        d1 = os.path.join(tmp, "a")
+        os.makedirs(d1)
+        for r in rows[:7]:
+            st = dict(sequence=r["sequence"], scribble_iter=r["scribble_iter"], n_interaction=r["n_interaction"])
+            nst = dict(sequence=r["sequence"], scribble_iter=r["scribble_iter"], n_interaction=r["n_interaction_next"])
+            mem.push(st, r["action"], nst, r["reward_step"], r["reward_done"], r["done"], r["state_iou"],
+                     r["next_state_iou"], r["annotated_frames"], r["next_annotated_frames"])
+            mem.push_to_csv(d1)
+        out["push_csv"] = open(os.path.join(d1, "memory_pool.csv")).read()
+        out["push_position"] = mem.position
+        out["push_len"] = len(mem)
+        out["push_actions_in_ring"] = [int(t.action) for t in mem.memory]
+        # (2) load_from_csv with the per-sequence filter
+        import pandas as pd
+        src = os.path.join(tmp, "pretrain.csv")
+        pd.DataFrame(rows, columns=mem.COLUMNS).to_csv(src)
+        out["pretrain_csv"] = open(src).read()
+        mem2 = ReplayMemory(8)                       # capacity truncates the 9 rows to 8 first
+        d2 = os.path.join(tmp, "b")
+        mem2.load_from_csv(src, d2, sample_th=0.05)
+        out["load_seq_list"] = list(mem2.seq_list)
+        out["load_capacity"] = int(mem2.capacity)
+        out["load_len"] = len(mem2)
+        out["load_position"] = int(mem2.position)
+        out["load_csv"] = open(os.path.join(d2, "memory_pool.csv")).read()
+        out["load_actions"] = [int(t.action) for t in mem2.memory]
+        # (3) the real minibatch source: dataset + DataLoader collation
+        root = os.path.join(tmp, "DAVIS")
+        os.makedirs(os.path.join(root, "ImageSets", "2017"))
+        with open(os.path.join(root, "ImageSets", "2017", "train.txt"), "w") as f:
+            f.write("\n".join(sorted({r["sequence"] for r in rows})) + "\n")
+        np.random.seed(0)
+        ds = DAVIS2017AgentTrain(split="train", db_root_dir=root, save_result_dir=d2, memory_size=100,
+                                 seq_list=mem2.seq_list)
+        loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False)
+        batch = next(iter(loader))
+        out["ds_len"] = len(ds)
+        out["batch"] = {k: dict(dtype=str(v.dtype), shape=list(v.shape), values=v.double().numpy().tolist())
+                        for k, v in batch.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    with open(os.path.join(HERE, "replay_fixtures.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("replay_fixtures.json", {k: (v if not isinstance(v, (str, dict)) else "...") for k, v in out.items()})
+
+
+# ----------------------------------------------------------------------------- recommendation glue known answers
+def make_glue():
+    import pandas as pd
+    from utils import utils_agent as ua
+    out = {}
+    v = np.array([0.7, 0.2, 0.9, 0.1, 0.5, 0.3])
+    out["select"] = [
+        dict(metric="worst", prev=[3], got=int(ua.select_next_frame(v.copy(), metric="worst", prev_frames=[3]))),
+        dict(metric="worst", prev=[3, 1, 5], got=int(ua.select_next_frame(v.copy(), metric="worst", prev_frames=[3, 1, 5]))),
+        dict(metric="worst", prev=list(range(6)), got=int(ua.select_next_frame(v.copy(), metric="worst", prev_frames=list(range(6))))),
+        dict(metric="max", prev=[2], got=int(ua.select_next_frame(v.copy(), metric="max", prev_frames=[2]))),
+        dict(metric="min", prev=None, got=int(ua.select_next_frame(v.copy(), metric="min"))),
+    ]
+    np.random.seed(4)
+    out["select_random"] = [int(ua.select_next_frame(v, metric="random")) for _ in range(5)]
+    out["gen_subseq"] = [dict(args=list(a), got=[int(x) for x in ua.gen_subseq(*a)]) for a in [
+        (10, 50, 25, "consecutive"), (0, 50, 25, "consecutive"), (49, 50, 25, "consecutive"), (30, 40, 25, "consecutive"),
+        (7, 50, 8, "equal"), (0, 50, 8, "equal"), (49, 50, 8, "equal"), (3, 6, 8, "equal"), (20, 104, 8, "equal")]]
+    # goal_only_reward: 30 random-policy baselines for (sequence, n_interaction_next, scribble slot)
+    rs = np.random.RandomState(8)
+    rows = []
+    for k in range(30):
+        rows.append(dict(sequence="bear", n_interaction_next=3, scribble_iter=2 + 3 * k,
+                         next_state_iou="/".join(str(float(x)) for x in np.round(rs.uniform(0.4, 0.8, 5), 4))))
+    for k in range(10):                                   # distractors: other slot / interaction / sequence
+        rows.append(dict(sequence="bear", n_interaction_next=3, scribble_iter=1 + 3 * k, next_state_iou="0.1/0.1"))
+        rows.append(dict(sequence="bear", n_interaction_next=4, scribble_iter=2, next_state_iou="0.2/0.2"))
+        rows.append(dict(sequence="camel", n_interaction_next=3, scribble_iter=2, next_state_iou="0.3/0.3"))
+    df = pd.DataFrame(rows)
+    out["reward_df"] = rows
+    iou_new = np.round(rs.uniform(0.5, 0.9, 5), 4)
+    r_step, r_done = ua.goal_only_reward("bear", 3, 5, False, iou_new, df=df)
+    r_step2, r_done2 = ua.goal_only_reward("bear", 3, 5, True, iou_new, df=None)
+    out["reward"] = dict(iou_new=iou_new.tolist(), step=int(r_step), done=float(r_done), step_repeat=int(r_step2),
+                         done_nodf=float(r_done2))
+    with open(os.path.join(HERE, "glue_fixtures.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("glue_fixtures.json", out["select"], out["reward"]["done"])
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["brain", "dqn", "assess", "replay", "glue"]
     os.chdir("/tmp")

@@ -1,0 +1,72 @@
+"""The C-ABI shared library loads and exports every symbol include/ivosw.h declares (no compute, no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from ivos_w_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ivosw.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ivosw_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def handle():
+    if not L.available():
+        import __graft_entry__ as g
+        g.build()
+    return ctypes.CDLL(L.LIB_PATH)
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(L.SIGNATURES)
+
+
+def test_every_declared_symbol_is_exported(handle):
+    missing = [s for s in declared_symbols() if not hasattr(handle, s)]
+    assert not missing, missing
+
+
+def test_host_only_queries(handle):
+    lib = L.lib()
+    assert lib.ivosw_version() >= 100
+    assert lib.ivosw_brain_ws_bytes(128, 25) > 0 and lib.ivosw_brain_ws_bytes(0, 25) == 0
+    assert lib.ivosw_dqn_ws_bytes(128, 25) > lib.ivosw_brain_ws_bytes(128, 25)
+    assert lib.ivosw_assess_packed_bytes(L.BF16) < lib.ivosw_assess_packed_bytes(L.F32)
+    assert lib.ivosw_assess_packed_bytes(7) == 0
+    assert lib.ivosw_assess_ws_bytes(L.BF16, 256, 480, 854, 0) > 0
+    assert lib.ivosw_assess_dominant_kernel(L.BF16).decode() == "conv_igemm"
+
+
+def test_argument_errors_do_not_touch_the_gpu(handle):
+    lib = L.lib()
+    assert lib.ivosw_brain_forward(None, None, 1, 1, None, None, 0, None) == -1
+    assert b"null" in lib.ivosw_last_error()
+    assert lib.ivosw_clamp_adam(None, None, None, None, 10, 1, 0.0, 0.9, 0.999, 1e-8, 0.0, 1.0, 1.0, None) == -1
+    assert lib.ivosw_assess_forward(None, 1, None, None, 1, 480, 854, None, None, 0, 0, 0, None, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from ivos_w_amd.models.agent import Brain
+    from ivos_w_amd.models.assessment import AssessNet
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Brain()(torch.zeros(1, 4, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        AssessNet().eval()(torch.zeros(1, 3, 32, 32), torch.zeros(1, 32, 32))
+
+
+def test_product_code_never_imports_the_oracle():
+    bad = []
+    for base in (os.path.join(ROOT, "ivos-w_amd"),):
+        for dp, _, fs in os.walk(base):
+            for f in fs:
+                if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, f)).read(), re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
