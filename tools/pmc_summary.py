@@ -1,0 +1,38 @@
+"""HBM traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the
+same command).  Units/corrections per MI355X_MICROARCH.md §HBM: both counters are in KiB; on gfx950 FETCH_SIZE reports
+half the bytes of wide coalesced streaming reads, so reads are doubled; WRITE_SIZE is taken as is (uncalibrated).
+usage: pmc_summary.py fetch_counter_collection.csv write_counter_collection.csv [family] [steps]"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = agg[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    fam = sys.argv[3] if len(sys.argv) > 3 else "conv_igemm"
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    print("# HBM traffic from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE as reported), KiB -> bytes")
+    print(f"{'calls':>7} {'read_GB':>9} {'write_GB':>9} {'MB/launch':>10}  kernel")
+    tot = [0, 0.0, 0.0]
+    for k in sorted(f, key=lambda k: -f[k][1]):
+        rd, wr = 2 * f[k][1] * 1024, w.get(k, [0, 0.0])[1] * 1024
+        print(f"{f[k][0]:7d} {rd/1e9:9.3f} {wr/1e9:9.3f} {(rd+wr)/max(f[k][0],1)/1e6:10.2f}  {k[:110]}")
+        if fam in k:
+            tot[0] += f[k][0]; tot[1] += rd; tot[2] += wr
+    print(f"\n# family *{fam}*: {tot[0]} launches, read {tot[1]/1e9:.3f} GB, write {tot[2]/1e9:.3f} GB, "
+          f"{(tot[1]+tot[2])/max(tot[0],1)/1e6:.2f} MB per launch, {(tot[1]+tot[2])/steps/1e9:.3f} GB per step ({steps} steps profiled)")
+
+
+if __name__ == "__main__":
+    main()
