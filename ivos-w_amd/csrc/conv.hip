@@ -29,12 +29,17 @@ constexpr int ROWB = 128;  // bytes per tile row per K-tile
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // epilogue phase 2: 8 consecutive channels per thread: + bias (+ residual) -> ReLU -> 16/32-B stores
-template <typename T, int BM, int BN, int NT = 256>
-__device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* Cs, int m0, int n0, int M, int tid) {
+template <typename T, int BM, int BN, int NT = 256, bool PRE = false>
+__device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* Cs, int m0, int n0, int M, int tid,
+                                               const uint4* pre = nullptr) {
     constexpr int ES = (int)sizeof(T);
     constexpr int CPR = BN / 8;  // 8-channel groups per row
+    static_assert(NT % CPR == 0, "a thread keeps one channel group across its items");
     T* Y = static_cast<T*>(p.y);
     const T* R = static_cast<const T*>(p.res);
+    // the thread's 8 output channels are the same for all of its items: one bias fetch
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + (tid % CPR) * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + (tid % CPR) * 8 + 4);
 #pragma unroll
     for (int it = 0; it < (BM * CPR) / NT; ++it) {
         const int item = it * NT + tid;
@@ -44,13 +49,12 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
         const int n = n0 + cg * 8;
         const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
         float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
         const long o = (long)m * p.Cout + n;
         if constexpr (ES == 2) {
             if (R) {
-                const uint4 rr = *reinterpret_cast<const uint4*>(R + o);
+                uint4 rr;
+                if constexpr (PRE) rr = pre[it]; else rr = *reinterpret_cast<const uint4*>(R + o);
                 const uint32_t w4[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -350,6 +354,25 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // residual tile -> registers before anything else (bf16: 16 B per item): its HBM/L2 latency hides under the
+    // whole K loop instead of sitting in the epilogue.  These loads are older than every DMA, and loads return
+    // in order, so the counted vmcnt waits below stay valid.
+    constexpr bool PRE = (ES == 2);
+    constexpr int ITEMS = (BM * (BN / 8)) / (NW * 64);
+    uint4 rres[PRE ? ITEMS : 1];
+    if constexpr (PRE) {
+        if (p.res) {
+            const T* R = static_cast<const T*>(p.res);
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = it * (NW * 64) + tid;
+                const int row = item / (BN / 8), cg = item - row * (BN / 8);
+                const int m = min(m0 + row, M - 1);   // clamp instead of branching: a predicated load would be waited for at once
+                rres[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.Cout + n0 + cg * 8);
+            }
+        }
+    }
+
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < nk) issue(s, s);
@@ -416,7 +439,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
                 Cs[row * BN + col] = acc[i][j][r];
             }
     __syncthreads();
-    epilogue_store<T, BM, BN, NW * 64>(p, Cs, m0, n0, M, tid);
+    epilogue_store<T, BM, BN, NW * 64, PRE>(p, Cs, m0, n0, M, tid, rres);
 }
 
 template <typename T, bool STEM>
@@ -432,8 +455,11 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
         const int nk = a.KH * a.KW * a.Cin / (128 / (int)sizeof(T));
         if (a.Cout % 128 == 0) {
             const int grid = ((M + 255) / 256) * (a.Cout / 128);
-            if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 2>), dim3(grid), dim3(512), 0, st, a);
+            if (nk >= 3) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
+            else {  // K <= 128: bound by the output/residual stream -> 128x128 tiles, 64 KB LDS, 2 workgroups per CU
+                const int g2 = ((M + 127) / 128) * (a.Cout / 128);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 2>), dim3(g2), dim3(512), 0, st, a);
+            }
         } else {  // Cout == 64 layers: 256 x 64 tile
             const int grid = ((M + 255) / 256) * (a.Cout / 64);
             if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 3>), dim3(grid), dim3(512), 0, st, a);
