@@ -1,7 +1,7 @@
 // AssessNet.forward on the MI355X: plan of the 54-conv tower, weight packing, chunked execution.
 //
 // Reference: AssessNet.forward (models/assessment.py:164-182), Encoder (:12-63), torchvision ResNet-50 v1.5.
-// Frames run through the whole tower in chunks (default 32 bf16 / 16 fp32) so that the layer-to-layer
+// Frames run through the whole tower in chunks (default 64 bf16 / 16 fp32) so that the layer-to-layer
 // activations of a chunk (<= ~2 MB per frame per tensor) stay resident in the 256 MiB Infinity Cache instead
 // of making a round trip to HBM between every pair of layers.
 #include <algorithm>
@@ -91,7 +91,7 @@ constexpr size_t E_OUT[4] = {64 * 64 * 256, 32 * 32 * 512, 16 * 16 * 1024, 8 * 8
 // Chunk schedule.  Stage s (res2..res5) runs on c0 * 2^s frames at a time: every stage halves H and W and
 // doubles C, so doubling the frames per launch keeps the per-stage working set constant (c0 * 2 MB bf16 per
 // tensor: Infinity-Cache resident) while every conv launch still has >= 512 workgroups for the 256 CUs.
-static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 32 : 16; }
+static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 64 : 16; }
 
 struct Bufs {
     float* yxhw; int32_t* box; float* pooled;

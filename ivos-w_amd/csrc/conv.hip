@@ -13,6 +13,8 @@
 // 16-lane ds_read_b128 groups are bank-conflict free.  bf16 mode: v_mfma_f32_32x32x16_bf16; fp32 parity
 // mode: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  The accumulator tile goes through LDS once so that
 // global stores (and residual loads) are full 16-B-per-lane row segments.
+#include <stdlib.h>
+
 #include <utility>
 #include <vector>
 
@@ -51,6 +53,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
         const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
         float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
         const long o = (long)m * p.Cout + n;
+        if (p.debug & 1) { if (v0.x == 1.2345e30f) Y[o] = T(0); continue; }
         if constexpr (ES == 2) {
             if (R) {
                 uint4 rr;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();   // every wave's share of tile kt has landed; every wave is done with tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + S - 1 < nk) issue(kt + S - 1, fill);   // refill the slot tile kt-1 just vacated
+        if (kt + S - 1 < nk && !(p.debug & 4)) issue(kt + S - 1, fill);   // refill the slot tile kt-1 just vacated
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
         u32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int ks, int buf) {
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
         for (int ks = 0; ks < 4; ++ks) {
             lds_wait();                                  // fragments of K-step ks are in registers
             if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);  // next K-step's reads fly under this step's MFMAs
+            if (p.debug & 2) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -455,7 +459,8 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
         const int nk = a.KH * a.KW * a.Cin / (128 / (int)sizeof(T));
         if (a.Cout % 128 == 0) {
             const int grid = ((M + 255) / 256) * (a.Cout / 128);
-            if (nk >= 3) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
+            static const int tune_nk = getenv("IVOSW_TUNE_NK") ? atoi(getenv("IVOSW_TUNE_NK")) : 8;
+            if (nk > tune_nk) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
             else {  // K <= 128: bound by the output/residual stream -> 128x128 tiles, 64 KB LDS, 2 workgroups per CU
                 const int g2 = ((M + 127) / 128) * (a.Cout / 128);
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 2>), dim3(g2), dim3(512), 0, st, a);
@@ -478,7 +483,10 @@ struct ConvProfiler {
 };
 static ConvProfiler g_prof;
 
-void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st) {
+void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
+    static const int dbg = getenv("IVOSW_DEBUG_CONV") ? atoi(getenv("IVOSW_DEBUG_CONV")) : 0;
+    ConvArgs a = a_in;
+    a.debug = dbg;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof.on) {
         if (g_prof.used == g_prof.ev.size()) {
