@@ -446,6 +446,181 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
     epilogue_store<T, BM, BN, NW * 64, PRE>(p, Cs, m0, n0, M, tid, rres);
 }
 
+// ---------------------------------------------------------------- wave-specialised variant (K-heavy layers)
+// Same ring / swizzle / epilogue, but LW extra waves (one per SIMD) do nothing except issue the LDS-DMA and count
+// it: an LDS-DMA wave-instruction occupies its wave's issue slot for ~60-180 cycles, which the in-order compute
+// waves above pay in front of their MFMAs.  Here the NW compute waves only run {barrier, ds_read, MFMA}.
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S, int LW>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_kernel(ConvArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int KE = ROWB / ES, CE = 16 / ES;
+    constexpr int AG = BM / 8 / LW, BG = BN / 8 / LW;  // 8-row groups per loader wave per K-tile
+    static_assert(AG * 8 * LW == BM && BG * 8 * LW == BN, "tile rows must split evenly over the loader waves");
+    constexpr int LPT = AG + BG;
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int LDS_BYTES = (S * STAGE_BYTES > EPI_BYTES) ? S * STAGE_BYTES : EPI_BYTES;
+    static_assert(S >= 2 && S <= 4, "ring depth");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbn = p.Cout / BN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = L % nbn, tile_m = L / nbn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int M = p.B * p.Ho * p.Wo;
+    const int K = p.KH * p.KW * p.Cin;
+    const int nk = K / KE;
+
+    if (wave >= NW) {
+        // ================= loader wave =================
+        const int lw = wave - NW;
+        const T* X = static_cast<const T*>(p.x);
+        const T* Wt = static_cast<const T*>(p.w);
+        const T* zeros = static_cast<const T*>(p.zeros);
+        const int ctiles = p.Cin / KE;
+        const int rsub = lane >> 3, cpos = lane & 7;
+        long abase[AG];
+        int aiy[AG], aix[AG], achunk[AG];
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            const int row = (lw * AG + i) * 8 + rsub;
+            achunk[i] = (cpos ^ ((row >> 1) & 7)) * CE;
+            const int m = m0 + row;
+            if (m < M) {
+                const int b = m / (p.Ho * p.Wo);
+                const int rem = m - b * (p.Ho * p.Wo);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                aiy[i] = oy * p.stride - p.pad;
+                aix[i] = ox * p.stride - p.pad;
+                abase[i] = (long)b * p.H * p.W * p.Cin;
+            } else {
+                aiy[i] = -100000; aix[i] = -100000; abase[i] = 0;
+            }
+        }
+        const T* bsrc[BG];
+#pragma unroll
+        for (int i = 0; i < BG; ++i) {
+            const int row = (lw * BG + i) * 8 + rsub;
+            bsrc[i] = Wt + (long)(n0 + row) * K + (cpos ^ ((row >> 1) & 7)) * CE;
+        }
+        auto issue = [&](int kt, int stage) {
+            const int tap = kt / ctiles, c0 = (kt - tap * ctiles) * KE;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            unsigned char* sb = lds + stage * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < AG; ++i) {
+                const int iy = aiy[i] + ky, ix = aix[i] + kx;
+                const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const T* src = ok ? X + abase[i] + ((long)iy * p.W + ix) * p.Cin + c0 + achunk[i] : zeros;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (lw * AG + i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BG; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(bsrc[i] + (long)kt * KE), (lptr_t)(sb + BM * ROWB + (lw * BG + i) * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < nk) issue(s, s);
+        int fill = S - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = min(S - 2, nk - 1 - kt);
+            if (ahead >= 2) wait_vmcnt<2 * LPT>();
+            else if (ahead == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // tile kt landed (all loaders); compute waves are done with tile kt-1
+            if (kt + S - 1 < nk) issue(kt + S - 1, fill);
+            fill = (fill + 1 == S) ? 0 : fill + 1;
+        }
+        __builtin_amdgcn_s_barrier();       // matches the two epilogue barriers of the compute waves
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ================= compute wave =================
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    constexpr bool PRE = (ES == 2);
+    constexpr int ITEMS = (BM * (BN / 8)) / (NW * 64);
+    uint4 rres[PRE ? ITEMS : 1];
+    if constexpr (PRE) {
+        if (p.res) {
+            const T* R = static_cast<const T*>(p.res);
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = it * (NW * 64) + tid;
+                const int row = item / (BN / 8), cg = item - row * (BN / 8);
+                const int m = min(m0 + row, M - 1);
+                rres[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.Cout + n0 + cg * 8);
+            }
+        }
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
+        u32x4 fa[2][TM], fb[2][TN];
+        auto frag_read = [&](int ks, int buf) {
+            const int ch = 2 * ks + lhalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, ch));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[buf][j] = lds_read_b128(b_base + swz((wn * TN + j) * 32 + lrow, ch));
+        };
+        frag_read(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            lds_wait();
+            if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);
+            if (p.debug & 2) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const u32x4 av = fa[ks & 1][i], bv = fb[ks & 1][j];
+                    if constexpr (ES == 2) {
+                        union { u32x4 u; bf16x8 v; } ua, ub;
+                        ua.u = av; ub.u = bv;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.x), __uint_as_float(bv.x), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.y), __uint_as_float(bv.y), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.z), __uint_as_float(bv.z), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av.w), __uint_as_float(bv.w), acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+        stage = (stage + 1 == S) ? 0 : stage + 1;
+    }
+    __builtin_amdgcn_s_barrier();  // every compute wave is done reading the ring (loaders have nothing in flight)
+    asm volatile("" ::: "memory");
+    float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const int col = (wn * TN + j) * 32 + lrow;
+                Cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();               // second epilogue barrier (with the LDS-write drain)
+    epilogue_store<T, BM, BN, NW * 64, PRE>(p, Cs, m0, n0, M, tid, rres);
+}
+
 template <typename T, bool STEM>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
     const int M = a.B * a.Ho * a.Wo;
@@ -460,14 +635,18 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
         if (a.Cout % 128 == 0) {
             const int grid = ((M + 255) / 256) * (a.Cout / 128);
             static const int tune_nk = getenv("IVOSW_TUNE_NK") ? atoi(getenv("IVOSW_TUNE_NK")) : 8;
-            if (nk > tune_nk) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
+            static const int use_ws = getenv("IVOSW_TUNE_WS") ? atoi(getenv("IVOSW_TUNE_WS")) : 1;
+            if (nk > tune_nk && use_ws) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 4>), dim3(grid), dim3(768), 0, st, a);
+            else if (nk > tune_nk) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
             else {  // K <= 128: bound by the output/residual stream -> 128x128 tiles, 64 KB LDS, 2 workgroups per CU
                 const int g2 = ((M + 127) / 128) * (a.Cout / 128);
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 2>), dim3(g2), dim3(512), 0, st, a);
             }
         } else {  // Cout == 64 layers: 256 x 64 tile
             const int grid = ((M + 255) / 256) * (a.Cout / 64);
-            if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 3>), dim3(grid), dim3(512), 0, st, a);
+            static const int use_ws64 = getenv("IVOSW_TUNE_WS") ? atoi(getenv("IVOSW_TUNE_WS")) : 1;
+            if (nk >= 4 && use_ws64) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 1, 3, 4>), dim3(grid), dim3(768), 0, st, a);
+            else if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 3>), dim3(grid), dim3(512), 0, st, a);
             else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 2>), dim3(grid), dim3(512), 0, st, a);
         }
     }
