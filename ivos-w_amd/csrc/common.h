@@ -61,6 +61,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair (lo in bits 0..15), round-to-nearest-even in hardware: v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    union { bf16x2_t b; uint32_t u; } x;
+    x.b = __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t);
+    return x.u;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float load(const float* p) { return *p; }

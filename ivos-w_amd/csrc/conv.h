@@ -16,6 +16,27 @@ struct ConvArgs {
 };
 
 void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st);
+
+// one whole identity bottleneck (1x1 -> 3x3 -> 1x1 + residual), bf16, fused in one kernel (bottleneck.hip)
+struct BneckArgs {
+    const void* x;       // NHWC [B,H,W,Cin]; also the residual
+    void* y;             // NHWC [B,H,W,4*Cmid]
+    const void* wa; const float* ba;   // [Cmid][Cin]      packed as by launch_pack_conv
+    const void* wb; const float* bb;   // [Cmid][9*Cmid]
+    const void* wc; const float* bc;   // [4*Cmid][Cmid]
+    const void* zeros;   // >= 256 B of device zeros
+    int B, H, W, Cin, Cmid;
+    unsigned long long* ts;  // optional [grid][16] s_memtime stamps at the phase boundaries (ivosw_bneck_probe), else null
+    int stagger;         // > 0: odd first-round workgroups start stagger x 8128 cycles late (tunable STAGGER)
+    int debug;           // ablation bits (tunable BDBG): 1 no residual read, 2 no stores, 4 K-tile 0 only (L2-hot A), 8 no MFMA
+};
+void* prof_begin(const ConvArgs& a, int es, hipStream_t st);   // measurement hook (ivosw_profile_*), see conv.hip
+void prof_end(void* tok, hipStream_t st);
+bool bneck_fusable(const BneckArgs& a);
+void launch_bneck(const BneckArgs& a, hipStream_t st);
+
+// runtime tunables (capi.cpp): value of IVOSW_TUNE_<KEY> from the environment unless ivosw_tune_set() overrode it
+int tune_get(const char* key, int dflt);
 void launch_pack_conv(const float* w, const float* g, const float* b, const float* rm, const float* rv, int Cout, int Cin,
                       int KH, int KW, int dtype, void* ow, float* ob, hipStream_t st);
 void launch_pack_stem(const float* w3, const float* w1, const float* g, const float* b, const float* rm, const float* rv,

@@ -20,15 +20,10 @@
 
 #include "common.h"
 #include "conv.h"
+#include "mfma_tile.h"
 
 namespace ivosw {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int ROWB = 128;  // bytes per tile row per K-tile
-
-__device__ __forceinline__ int swz(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // epilogue phase 2: 8 consecutive channels per thread: + bias (+ residual) -> ReLU -> 16/32-B stores
 template <typename T, int BM, int BN, int NT = 256, bool PRE = false>
@@ -70,7 +65,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
             for (int q = 0; q < 4; ++q) {
                 float a = v[2 * q], b = v[2 * q + 1];
                 if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-                pk[q] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+                pk[q] = pack2_bf16(a, b);
             }
             *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         } else {
@@ -255,26 +250,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 // lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied on the SOURCE side: the lane that
 // lands on chunk position p of row r fetches chunk p ^ ((r>>1)&7); reads use the same involution.  Zero padding:
 // out-of-image taps fetch from a 16-B page of zeros.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-
-// Fragment reads are inline asm: hipcc cannot prove a ds_read does not alias the in-flight LDS-DMA of another
-// ring slot and would drain the whole pipeline (s_waitcnt vmcnt(0)) in front of every K-step.  Reads issued this
-// way are not tracked by the compiler: lds_wait() (lgkmcnt(0) + scheduling fence) must precede their first use.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-__device__ __forceinline__ void lds_wait() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
 template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(ConvArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;
@@ -662,32 +637,39 @@ struct ConvProfiler {
 };
 static ConvProfiler g_prof;
 
+// begin/end of one profiled launch: `a` describes the layer for the report (KH == 0 marks a fused bottleneck:
+// Cin -> Cout/4 -> Cout/4 (3x3) -> Cout + residual)
+void* prof_begin(const ConvArgs& a, int es, hipStream_t st) {
+    if (!g_prof.on) return nullptr;
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t x, y;
+        (void)hipEventCreate(&x);
+        (void)hipEventCreate(&y);
+        g_prof.ev.emplace_back(x, y);
+    }
+    hipEvent_t e0 = g_prof.ev[g_prof.used].first, e1 = g_prof.ev[g_prof.used].second;
+    if (g_prof.args.size() <= g_prof.used) { g_prof.args.resize(g_prof.used + 1); g_prof.es.resize(g_prof.used + 1); }
+    g_prof.args[g_prof.used] = a;
+    g_prof.es[g_prof.used] = es;
+    ++g_prof.used;
+    (void)hipEventRecord(e0, st);
+    return e1;
+}
+void prof_end(void* tok, hipStream_t st) {
+    if (tok) (void)hipEventRecord(static_cast<hipEvent_t>(tok), st);
+}
+
 void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
     static const int dbg = getenv("IVOSW_DEBUG_CONV") ? atoi(getenv("IVOSW_DEBUG_CONV")) : 0;
     ConvArgs a = a_in;
     a.debug = dbg;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g_prof.on) {
-        if (g_prof.used == g_prof.ev.size()) {
-            hipEvent_t x, y;
-            (void)hipEventCreate(&x);
-            (void)hipEventCreate(&y);
-            g_prof.ev.emplace_back(x, y);
-        }
-        e0 = g_prof.ev[g_prof.used].first;
-        e1 = g_prof.ev[g_prof.used].second;
-        if (g_prof.args.size() <= g_prof.used) { g_prof.args.resize(g_prof.used + 1); g_prof.es.resize(g_prof.used + 1); }
-        g_prof.args[g_prof.used] = a;
-        g_prof.es[g_prof.used] = (dtype == IVOSW_BF16) ? 2 : 4;
-        ++g_prof.used;
-        (void)hipEventRecord(e0, st);
-    }
+    void* tok = prof_begin(a, (dtype == IVOSW_BF16) ? 2 : 4, st);
     if (dtype == IVOSW_BF16) {
         if (stem) launch_conv_t<bf16_t, true>(a, st); else launch_conv_t<bf16_t, false>(a, st);
     } else {
         if (stem) launch_conv_t<float, true>(a, st); else launch_conv_t<float, false>(a, st);
     }
-    if (e1) (void)hipEventRecord(e1, st);
+    prof_end(tok, st);
 }
 
 // ---------------------------------------------------------------- weight packing (BN fold + K-major repack)
@@ -786,7 +768,7 @@ __global__ void maxpool_kernel(const T* __restrict__ x, int B, int H, int W, int
     if constexpr (sizeof(T) == 2) {
         uint32_t pk[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = (uint32_t)f32_to_bf16(m[2 * q]) | ((uint32_t)f32_to_bf16(m[2 * q + 1]) << 16);
+        for (int q = 0; q < 4; ++q) pk[q] = pack2_bf16(m[2 * q], m[2 * q + 1]);
         *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     } else {
         *reinterpret_cast<float4*>(o) = make_float4(m[0], m[1], m[2], m[3]);
@@ -883,8 +865,10 @@ extern "C" int ivosw_profile_report(char* buf, size_t cap) {
         if (off + 160 > cap) break;
         const ConvArgs& a = r.a;
         const double M = (double)a.B * a.Ho * a.Wo;
-        const double flops = 2.0 * M * a.Cout * a.KH * a.KW * a.Cin;
-        const double bytes = ((double)a.B * a.H * a.W * a.Cin + M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * a.KH * a.KW * a.Cin) * r.es;
+        const double cm = a.Cout / 4.0;
+        const double flops = a.KH ? 2.0 * M * a.Cout * a.KH * a.KW * a.Cin : 2.0 * M * (a.Cin * cm + 9.0 * cm * cm + cm * a.Cout);
+        const double bytes = a.KH ? ((double)a.B * a.H * a.W * a.Cin + M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * a.KH * a.KW * a.Cin) * r.es
+                                  : (M * (a.Cin + a.Cout) + a.Cin * cm + 13.0 * cm * cm) * r.es;
         const double t = r.ms / r.n * 1e-3;
         off += snprintf(buf + off, cap - off, "%5d %4d %5d %5d %2d %2d %3d %5d %9.2f %9.3f %8.1f %8.1f\n", a.B, a.H, a.Cin, a.Cout, a.KH, a.stride,
                         a.res ? 1 : 0, r.n, r.ms / r.n * 1e3, r.ms, flops / t / 1e12, bytes / t / 1e9);

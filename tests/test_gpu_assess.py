@@ -111,6 +111,35 @@ def test_bf16_scores_vs_reference_golden(dev, gold, net16):
     print(f"bf16 worst relative score error vs reference: {worst:.2e}")
 
 
+def test_fused_bottleneck_matches_layerwise(dev, net16, net32):
+    """bf16 mode: the fused whole-bottleneck kernels (tunable FUSE=1, default) against the layer-by-layer
+    kernels (FUSE=0) on every stage output, and both against the fp32 path.  The two bf16 paths round the
+    same intermediates (t1, t2, block outputs) to bf16, so they may differ by bf16 ulps only."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    _, _, ttf, ttp = inputs(dev, 8, True)
+    try:
+        for nm in ("res2", "res3", "res4", "res5"):
+            lib.ivosw_tune_set(b"FUSE", 1)
+            _, a = net16.forward_tap(ttf, ttp, nm)
+            lib.ivosw_tune_set(b"FUSE", 0)
+            _, b = net16.forward_tap(ttf, ttp, nm)
+            _, r = net32.forward_tap(ttf, ttp, nm)
+            a, b, r = a.float().cpu().numpy(), b.float().cpu().numpy(), r.cpu().numpy()
+            scale = np.abs(r).max()
+            err_a, err_b = np.abs(a - r).max() / scale, np.abs(b - r).max() / scale
+            print(f"{nm}: fused vs fp32 {err_a:.3e}, layerwise vs fp32 {err_b:.3e}, fused vs layerwise {np.abs(a - b).max() / scale:.3e}")
+            assert err_a < 3e-2 and err_a < 2.0 * err_b + 1e-3, nm    # as close to fp32 as the unfused bf16 path
+            np.testing.assert_allclose(a.mean(), r.mean(), rtol=2e-3, err_msg=nm)
+        lib.ivosw_tune_set(b"FUSE", 1)
+        sa = net16(ttf, ttp).cpu().numpy()
+        lib.ivosw_tune_set(b"FUSE", 0)
+        sb = net16(ttf, ttp).cpu().numpy()
+        np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
+    finally:
+        lib.ivosw_tune_set(b"FUSE", 1)
+
+
 def test_full_size_properties(dev, net16, net32):
     """B=64 at 480p: results are independent of batch composition/chunking (each frame is an independent unit),
     and the bf16 path ranks frames like the fp32 path up to its own noise."""
