@@ -194,29 +194,31 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
             asm volatile("" ::: "memory");
             stamp(1 + kt);
             const unsigned w_base = lds_base + st, a_base = w_base + WK_BYTES;
-            u32x4 wf[2], pf[2][3];
-            auto frag_read = [&](int ks, int buf) {
+            // the whole K-tile's fragments at once (16 reads in flight, one wait): with one step of lookahead the
+            // ~300-400-cycle loaded LDS latency was exposed four times per K-tile
+            u32x4 wf[4], pf[4][3];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
                 const int ch = 2 * ks + lhalf;
-                wf[buf] = lds_read_b128(w_base + swz(ct * 32 + lrow, ch));
-                pf[buf][0] = lds_read_b128(a_base + swz(pq * 32 + lrow, ch));
-                pf[buf][1] = lds_read_b128(a_base + swz((pq + 4) * 32 + lrow, ch));
-                if (has3) pf[buf][2] = lds_read_b128(a_base + swz((pq + 8) * 32 + lrow, ch));
-            };
-            frag_read(0, 0);
+                wf[ks] = lds_read_b128(w_base + swz(ct * 32 + lrow, ch));
+                pf[ks][0] = lds_read_b128(a_base + swz(pq * 32 + lrow, ch));
+                pf[ks][1] = lds_read_b128(a_base + swz((pq + 4) * 32 + lrow, ch));
+                if (has3) pf[ks][2] = lds_read_b128(a_base + swz((pq + 8) * 32 + lrow, ch));
+            }
             if (wn == (kt >> 1)) {                   // this K-tile holds the residual of my store passes (cp = kt & 1)
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int it = 0; it < 4; ++it) rr[(kt & 1) * 2 + q][it] = lds_read_b128(a_base + rrow[q][it]);
             }
+            lds_wait();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                lds_wait();
-                if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);
-                acc[0] = mfma_dbg(wf[ks & 1], pf[ks & 1][0], acc[0], p.debug);
-                acc[1] = mfma_dbg(wf[ks & 1], pf[ks & 1][1], acc[1], p.debug);
-                if (has3) acc[2] = mfma_dbg(wf[ks & 1], pf[ks & 1][2], acc[2], p.debug);
+                acc[0] = mfma_dbg(wf[ks], pf[ks][0], acc[0], p.debug);
+                acc[1] = mfma_dbg(wf[ks], pf[ks][1], acc[1], p.debug);
+                if (has3) acc[2] = mfma_dbg(wf[ks], pf[ks][2], acc[2], p.debug);
             }
+            if (kt < 2) stamp(11 + 2 * kt);
             __builtin_amdgcn_s_barrier();            // every wave is done reading this stage
             asm volatile("" ::: "memory");
             if (kt == 0) issue_a(3, S0);
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
 #pragma unroll
                 for (int t = 6; t < 9; ++t) issue_wb(t);
             }
+            if (kt < 2) stamp(12 + 2 * kt);
         }
         stamp(5);
         // epilogue A: + bias, ReLU, zero outside the image (the 3x3 pads t1, not x), bf16 -> t1 (S0 is free)

@@ -12,6 +12,7 @@ struct ConvArgs {
     void* y;            // NHWC [B,Ho,Wo,Cout]
     const void* zeros;  // >= 16 B of device zeros: source of the zero-padding taps for the LDS-DMA loader
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
+    int nmajor;         // tile order of the wave-specialised kernel: 0 m-major, 1 n-major
     int debug;          // ablation bits (IVOSW_DEBUG_CONV, tuning only): 1 skip epilogue stores, 2 skip MFMA, 4 skip DMA after the first tile
 };
 

@@ -444,7 +444,10 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nbn = p.Cout / BN;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = L % nbn, tile_m = L / nbn;
+    // tile order: m-major (the n-tiles of one m-tile adjacent on one XCD: the A tile is fetched from HBM once) or
+    // n-major (an XCD keeps ONE weight slice in its L2 and walks the m-tiles: for slices too big to share an L2)
+    const int nbm = gridDim.x / nbn;
+    const int tile_n = p.nmajor ? L / nbm : L % nbn, tile_m = p.nmajor ? L % nbm : L / nbn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int M = p.B * p.Ho * p.Wo;
     const int K = p.KH * p.KW * p.Cin;
@@ -663,6 +666,10 @@ void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
     static const int dbg = getenv("IVOSW_DEBUG_CONV") ? atoi(getenv("IVOSW_DEBUG_CONV")) : 0;
     ConvArgs a = a_in;
     a.debug = dbg;
+    {
+        const int nm = tune_get("NMAJOR", 0);       // 0 off, 1 all ws launches, 2 only 3x3
+        a.nmajor = (nm == 1) || (nm == 2 && a.KH == 3);
+    }
     void* tok = prof_begin(a, (dtype == IVOSW_BF16) ? 2 : 4, st);
     if (dtype == IVOSW_BF16) {
         if (stem) launch_conv_t<bf16_t, true>(a, st); else launch_conv_t<bf16_t, false>(a, st);

@@ -58,6 +58,8 @@ names = ["A tile0 landed", "A tile1 landed", "A tile2 landed", "A tile3 landed",
 print("phase            mean     p10     p90   (s_memtime ticks; 100 MHz => x24 shader cycles if constant clock)")
 for i, n in enumerate(names):
     print(f"{n:16s} {d[:, i].mean():8.0f} {np.percentile(d[:, i], 10):7.0f} {np.percentile(d[:, i], 90):7.0f}")
+print("K-tile 0: landed->computed %.0f, ->barrier+issue T3 %.0f | K-tile 1: landed->computed %.0f, ->barrier+issue Wb %.0f" % (
+    (t[:, 11] - t[:, 1]).mean(), (t[:, 12] - t[:, 11]).mean(), (t[:, 13] - t[:, 2]).mean(), (t[:, 14] - t[:, 13]).mean()))
 tot = t[:, 10] - t[:, 0]
 print(f"{'total':14s} {tot.mean():8.0f} {np.percentile(tot, 10):7.0f} {np.percentile(tot, 90):7.0f}")
 span = t[:, 10].max() - t[:, 0].min()

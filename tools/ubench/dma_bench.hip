@@ -14,7 +14,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // each wave: `iters` rounds of DEPTH x (1 KB DMA); row segment = 128 B, 8 rows per instruction, row stride `stride` bytes
 template <int DEPTH, bool DMA>
-__global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t footprint, int stride, int iters, unsigned* sink) {
+__global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t footprint, int stride, int iters, unsigned* sink, int mode = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     // block-private slice of the footprint so that different CUs read different lines
@@ -22,7 +22,8 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t foot
     const char* base = src + (size_t)blockIdx.x * slice;
     const size_t wave_span = slice / nw;
     const char* wb = base + (size_t)wave * wave_span;
-    const size_t lane_off = (size_t)(lane >> 3) * stride + (lane & 7) * 16;
+    const int row = lane >> 3;
+    const size_t lane_off = (size_t)row * stride + (((lane & 7) ^ ((mode & 1) ? ((row * 5 + wave) & 7) : 0)) * 16);
     const size_t step = (size_t)8 * stride;     // bytes consumed per instruction (8 rows)
     const size_t wrap = wave_span / step * step;
     size_t off = 0;
@@ -31,8 +32,11 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t foot
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const char* p = wb + off + lane_off;
+            if ((mode & 2) && d % 6 == 5) p = src;
+            if ((mode & 4) && row == 7) p = src;
             if constexpr (DMA) {
-                __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lds + (wave * DEPTH + d) * 1024), 16, 0, 0);
+                if (mode & 8) __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lds + (wave * DEPTH + d) * 1024), 16, 0, 16);   // sc1: bypass L1
+                else __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(lds + (wave * DEPTH + d) * 1024), 16, 0, 0);
             } else {
                 const uint4 v = *reinterpret_cast<const uint4*>(p);
                 acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
@@ -47,14 +51,14 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t foot
 }
 
 template <int DEPTH, bool DMA>
-static double run(const char* src, size_t footprint, int stride, int waves, int iters, unsigned* sink, int ncu) {
+static double run(const char* src, size_t footprint, int stride, int waves, int iters, unsigned* sink, int ncu, int mode = 0) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t ldsb = DMA ? (size_t)waves * DEPTH * 1024 : 0;
     hipFuncSetAttribute((const void*)fill_kernel<DEPTH, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((fill_kernel<DEPTH, DMA>), dim3(ncu), dim3(waves * 64), ldsb, 0, src, footprint, stride, iters, sink);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((fill_kernel<DEPTH, DMA>), dim3(ncu), dim3(waves * 64), ldsb, 0, src, footprint, stride, iters, sink, mode);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((fill_kernel<DEPTH, DMA>), dim3(ncu), dim3(waves * 64), ldsb, 0, src, footprint, stride, iters, sink);
+    hipLaunchKernelGGL((fill_kernel<DEPTH, DMA>), dim3(ncu), dim3(waves * 64), ldsb, 0, src, footprint, stride, iters, sink, mode);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -72,13 +76,12 @@ int main() {
     hipMalloc(&sink, 64);
     hipMemset(src, 1, cap);
     printf("%-5s %-6s %-9s %-7s %-6s %10s %12s\n", "kind", "waves", "footprint", "stride", "depth", "GB/s", "B/clk/CU@2.1");
-    // (2) channel aliasing: 128-B row segments at stride S (only the first 128 B of every S bytes are touched),
-    // touched bytes per CU fixed at 64 KB (L1-thrashing, L2-resident: 16 MB touched in total) or HBM-sized
-    for (int stride : {128, 256, 512, 1024, 2048, 4096}) {
-        const size_t fp_l2 = (size_t)256 * 64 * 1024 * (stride / 128);
-        double a = run<8, true>(src, fp_l2, stride, 8, 400, sink, 256);
-        double h = (size_t)256 * 4096 * 1024 * (size_t)(stride / 128) <= cap ? run<8, true>(src, (size_t)256 * 4096 * 1024 * (stride / 128), stride, 8, 400, sink, 256) : 0;
-        printf("stride %-5d L2-resident: %8.0f GB/s %6.1f B/clk/CU | 1 GB touched: %8.0f GB/s %6.1f B/clk/CU\n", stride, a, a / 256 / 2.1, h, h / 256 / 2.1);
-    }
+    // (3) source-side details of the conv loaders: XOR-swizzled chunk order (1), shared-address dummy every 6th DMA (2), 1/8 zero rows (4)
+    for (int mode : {0, 8, 9})
+        for (int depth12 : {0, 1}) {
+            const size_t fp_l2 = (size_t)256 * 64 * 1024 * 4;
+            double a = depth12 ? run<12, true>(src, fp_l2, 512, 8, 300, sink, 256, mode) : run<6, true>(src, fp_l2, 512, 8, 600, sink, 256, mode);
+            printf("mode %d depth %-2d stride 512 L2-resident: %8.0f GB/s %6.1f B/clk/CU\n", mode, depth12 ? 12 : 6, a, a / 256 / 2.1);
+        }
     return 0;
 }
