@@ -129,11 +129,13 @@ int ivosw_profile_report(char* buf, size_t cap);
 /* Tuning/test hook: override a named integer tunable (otherwise read from the environment variable
  * IVOSW_TUNE_<KEY>).  Keys: FUSE (1 = whole-bottleneck fused kernels in bf16 mode, 0 = layer by layer), WS, NK. */
 int ivosw_tune_set(const char* key, int value);
-/* Tuning probe: ONE fused identity bottleneck (x [B,H,W,Cin] bf16 -> y [B,H,W,4*Cmid] bf16; weights packed
+/* Tuning probe: ONE fused bottleneck (wd/bd NULL: identity block, else the stride-1 downsample block)
+ * (x [B,H,W,Cin] bf16 -> y [B,H,W,4*Cmid] bf16; weights packed
  * K-major bf16 with fp32 biases as ivosw_assess_pack lays them out) with s_memtime stamps at the phase
  * boundaries of every workgroup: ts [B*(H/16)*(W/16)][16] uint64 on the device (may be NULL).             */
 int ivosw_bneck_probe(const void* x, void* y, const void* wa, const float* ba, const void* wb, const float* bb,
-                      const void* wc, const float* bc, const void* zeros, int B, int H, int W, int Cin, int Cmid,
+                      const void* wc, const float* bc, const void* wd, const float* bd, const void* zeros,
+                      int B, int H, int W, int Cin, int Cmid,
                       unsigned long long* ts, ivosw_stream_t stream);
 
 #ifdef __cplusplus

@@ -218,12 +218,16 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
                 launch_conv(q, dtype, false, st);
             };
-            if (dtype == IVOSW_BF16 && bp.ds < 0 && tune_get("FUSE", 1)) {
+            if (dtype == IVOSW_BF16 && (bp.ds < 0 || c2.stride == 1) && tune_get("FUSE", 1)) {
                 BneckArgs q{};
                 q.x = x; q.y = y; q.zeros = base + P.zero_off;
                 q.wa = base + c1.w_off; q.ba = reinterpret_cast<const float*>(base + c1.b_off);
                 q.wb = base + c2.w_off; q.bb = reinterpret_cast<const float*>(base + c2.b_off);
                 q.wc = base + c3.w_off; q.bc = reinterpret_cast<const float*>(base + c3.b_off);
+                if (bp.ds >= 0) {
+                    q.wd = base + P.convs[bp.ds].w_off;
+                    q.bd = reinterpret_cast<const float*>(base + P.convs[bp.ds].b_off);
+                }
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
                 if (bneck_fusable(q)) {
                     launch_bneck(q, st);

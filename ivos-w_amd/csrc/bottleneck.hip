@@ -27,7 +27,10 @@
 //   S0 [0, 50176)        K-tiles 0,3 -> t1 [0, 41472) -> exchange scratch / store staging of waves 0..5
 //   S1 [50176, 100352)   K-tile 1    -> Wb taps 0..5 -> t2 [50176, 82944) | scratch/staging of waves 6,7
 //   S2 [100352, 150528)  K-tile 2    -> Wc [100352, 133120) | Wb taps 6,7 | tap 8 runs to 157696
-//   [157696, 158720) DMA dummy, [161792, 163328) the three bias vectors
+//   [157696, 158720) DMA dummy, [160768, 163840) the bias vectors
+// Downsample block (DS: first block of res2, Cin 64, y = relu(Wc t2 + bc + Wd x + bd)): one K-tile in phase A, every
+// weight tap in flight from the first cycle, and phase C gets a second K-tile: the x centre rows are re-fetched
+// (L2-hot) next to Wd into the space t1 and the scratch vacated.
 #include <stdlib.h>
 
 #include "conv.h"
@@ -49,9 +52,11 @@ constexpr int T2_OFF = S1;
 constexpr int WC_OFF = S2;
 constexpr int WB_HI = WC_OFF + 256 * ROWB;      // 133120: taps 6..8
 constexpr int DUMMY_OFF = WB_HI + 3 * WK_BYTES; // 157696
-constexpr int BIAS_OFF = 161792;                // ba[64] | bb[64] | bc[256] fp32
+constexpr int BIAS_OFF = 160768;                // ba[64] | bb[64] | bc[256] | bd[256] fp32 | 512 B pad (3 x 1-KB DMA)
 constexpr int FUSED_LDS = 163840;
-static_assert(S1 + 6 * WK_BYTES <= S2 && DUMMY_OFF + 1024 <= BIAS_OFF && BIAS_OFF + 1536 <= FUSED_LDS, "LDS map");
+static_assert(S1 + 6 * WK_BYTES <= S2 && DUMMY_OFF + 1024 <= BIAS_OFF && BIAS_OFF + 3072 <= FUSED_LDS, "LDS map");
+// downsample variant, phase C: x centre rows (256 x 128 B) and the two 128-row halves of Wd
+constexpr int XC_OFF = 0, WD_OFF0 = 32768, WD_OFF1 = WB_HI;
 static_assert(S2 + WK_BYTES + 352 * ROWB <= FUSED_LDS, "fragment reads of the padded pixel tile stay inside LDS");
 
 __host__ __device__ constexpr int wb_slot(int t) { return t < 6 ? S1 + t * WK_BYTES : WB_HI + (t - 6) * WK_BYTES; }
@@ -72,10 +77,12 @@ __device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
 
 }  // namespace
 
-// identity bottleneck, mid width 64: x [B,H,W,CIN] -> y [B,H,W,256], CIN == 256
-template <int CIN>
+// bottleneck of mid width 64: x [B,H,W,CIN] -> y [B,H,W,256].  DS = false: identity block (CIN == 256, residual = x);
+// DS = true: downsample block (CIN == 64, residual = Wd x + bd, stride 1)
+template <int CIN, bool DS>
 __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
-    static_assert(CIN == 256, "identity block of res2: 4 K-tiles over a 3-stage ring");
+    static_assert((CIN == 256 && !DS) || (CIN == 64 && DS), "res2: identity blocks (4 K-tiles over a 3-stage ring) or the first block (1 K-tile)");
+    constexpr int NKA = CIN / 64;
     __shared__ __attribute__((aligned(16))) unsigned char lds[FUSED_LDS];  // the ONLY LDS object
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -143,14 +150,25 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
 
     // biases -> LDS (oldest DMAs of wave 0: every later counted wait covers them)
     if (wave == 0) {
+        const float* zf = reinterpret_cast<const float*>(zeros);
         const float* s0 = lane < 16 ? p.ba + lane * 4 : lane < 32 ? p.bb + (lane - 16) * 4 : p.bc + (lane - 32) * 4;
-        const float* s1 = lane < 32 ? p.bc + 128 + lane * 4 : reinterpret_cast<const float*>(zeros);
+        const float* s1 = lane < 32 ? p.bc + 128 + lane * 4 : DS ? p.bd + (lane - 32) * 4 : zf;
+        const float* s2 = (DS && lane < 32) ? p.bd + 128 + lane * 4 : zf;
         dma16(s0, lds + BIAS_OFF);
         dma16(s1, lds + BIAS_OFF + 1024);
+        dma16(s2, lds + BIAS_OFF + 2048);
     }
     issue_a(0, S0);
-    issue_a(1, S1);
-    issue_a(2, S2);
+    if constexpr (!DS) {
+        issue_a(1, S1);
+        issue_a(2, S2);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) issue_wb(t);
+        issue_wc();
+#pragma unroll
+        for (int t = 6; t < 9; ++t) issue_wb(t);
+    }
 
     // Store-pass geometry (phase C): lane = (pixel sub-row prr, 8-channel group u); pass (cp, q) covers pixel tile 2wm+q,
     // channels (4wn+2cp)*32 .. +64, i.e. exactly K-tile 2wn+cp of x: the residual is picked out of the ring stage of
@@ -184,18 +202,17 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            // DMA issue order per wave: T0 T1 T2 | T3 (after tile 0) | Wb0-5 (after tile 1) | Wc x4, Wb6-8 (after tile 2)
-            constexpr int younger[4] = {14, 14, 13, 13};
+        for (int kt = 0; kt < NKA; ++kt) {
+            // DMA issue order per wave.  identity: T0 T1 T2 | T3 (after tile 0) | Wb0-5 (after tile 1) | Wc x4, Wb6-8
+            // (after tile 2).  DS: T0, Wb0-5, Wc x4, Wb6-8 all up front.
+            constexpr int younger_id[4] = {14, 14, 13, 13};
             constexpr int stage[4] = {S0, S1, S2, S0};
             const int st = stage[kt];
-            wait_vmcnt_n(younger[kt]);
+            wait_vmcnt_n(DS ? 13 : younger_id[kt]);
             __builtin_amdgcn_s_barrier();            // K-tile kt landed for every wave
             asm volatile("" ::: "memory");
             stamp(1 + kt);
             const unsigned w_base = lds_base + st, a_base = w_base + WK_BYTES;
-            // the whole K-tile's fragments at once (16 reads in flight, one wait): with one step of lookahead the
-            // ~300-400-cycle loaded LDS latency was exposed four times per K-tile
             u32x4 wf[4], pf[4][3];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -205,11 +222,13 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
                 pf[ks][1] = lds_read_b128(a_base + swz((pq + 4) * 32 + lrow, ch));
                 if (has3) pf[ks][2] = lds_read_b128(a_base + swz((pq + 8) * 32 + lrow, ch));
             }
-            if (wn == (kt >> 1)) {                   // this K-tile holds the residual of my store passes (cp = kt & 1)
+            if constexpr (!DS) {
+                if (wn == (kt >> 1)) {               // this K-tile holds the residual of my store passes (cp = kt & 1)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) rr[(kt & 1) * 2 + q][it] = lds_read_b128(a_base + rrow[q][it]);
+                        for (int it = 0; it < 4; ++it) rr[(kt & 1) * 2 + q][it] = lds_read_b128(a_base + rrow[q][it]);
+                }
             }
             lds_wait();
 #pragma unroll
@@ -221,15 +240,17 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
             if (kt < 2) stamp(11 + 2 * kt);
             __builtin_amdgcn_s_barrier();            // every wave is done reading this stage
             asm volatile("" ::: "memory");
-            if (kt == 0) issue_a(3, S0);
-            if (kt == 1) {
+            if constexpr (!DS) {
+                if (kt == 0) issue_a(3, S0);
+                if (kt == 1) {
 #pragma unroll
-                for (int t = 0; t < 6; ++t) issue_wb(t);
-            }
-            if (kt == 2) {
-                issue_wc();
+                    for (int t = 0; t < 6; ++t) issue_wb(t);
+                }
+                if (kt == 2) {
+                    issue_wc();
 #pragma unroll
-                for (int t = 6; t < 9; ++t) issue_wb(t);
+                    for (int t = 6; t < 9; ++t) issue_wb(t);
+                }
             }
             if (kt < 2) stamp(12 + 2 * kt);
         }
@@ -353,6 +374,98 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
         stamp(8);
     }
 
+    if constexpr (DS) {
+        // ============================================================ phase C (DS): y = relu(Wc t2 + Wd x + bc + bd)
+        // second K-tile: x centre rows (re-fetched, L2-hot) and Wd land where t1 / the scratch were (free since the
+        // barrier above) while the first K-tile runs
+        {
+            const bf16_t* Wd = static_cast<const bf16_t*>(p.wd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = wave * 4 + i;
+                const int row = g * 8 + rsub;                       // centre pixel row / Wd output channel
+                const int sw = (cpos ^ ((row >> 1) & 7)) * 8;
+                dma16(X + (((long)b * p.H + y0 + (row >> 4)) * p.W + x0 + (row & 15)) * CIN + sw, lds + XC_OFF + g * 1024);
+                dma16(Wd + (long)row * 64 + sw, lds + (g < 16 ? WD_OFF0 + g * 1024 : WD_OFF1 + (g - 16) * 1024));
+            }
+        }
+        f32x16 acc[4][2];
+        {
+            u32x4 bq[4][4], bd[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bq[c][g] = lds_read_b128(lds_base + BIAS_OFF + 512 + ((4 * wn + c) * 32 + 8 * g + 4 * lhalf) * 4);
+                    bd[c][g] = lds_read_b128(lds_base + BIAS_OFF + 1536 + ((4 * wn + c) * 32 + 8 * g + 4 * lhalf) * 4);
+                }
+            lds_wait();
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][q][r] = __uint_as_float(bq[c][r >> 2][r & 3]) + __uint_as_float(bd[c][r >> 2][r & 3]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 1) {
+                wait_vmcnt_n(0);
+                __builtin_amdgcn_s_barrier();        // x centre rows + Wd landed for every wave
+                asm volatile("" ::: "memory");
+            }
+            const unsigned w_base = lds_base + (kt == 0 ? WC_OFF + 4 * wn * 32 * ROWB : (wn ? WD_OFF1 : WD_OFF0));
+            const unsigned p_base = lds_base + (kt == 0 ? T2_OFF : XC_OFF);
+            u32x4 wf[2][4], pf[2][2];
+            auto frag_read = [&](int ks, int buf) {
+                const int ch = 2 * ks + lhalf;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wf[buf][c] = lds_read_b128(w_base + swz(c * 32 + lrow, ch));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pf[buf][q] = lds_read_b128(p_base + swz((2 * wm + q) * 32 + lrow, ch));
+            };
+            frag_read(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                lds_wait();
+                if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc[c][q] = mfma_dbg(wf[ks & 1][c], pf[ks & 1][q], acc[c][q], p.debug);
+            }
+        }
+        stamp(9);
+        __builtin_amdgcn_s_barrier();                // every wave is done with t2 / x / Wc / Wd: their space is store staging
+        asm volatile("" ::: "memory");
+        float* stg = reinterpret_cast<float*>(lds + wave_scratch(wave));
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int slot = (8 * c + 2 * g + lhalf) ^ (lrow & 15);
+                        const f32x16& a = acc[2 * cp + c][q];
+                        *reinterpret_cast<float4*>(stg + lrow * 64 + slot * 4) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int pr = it * 8 + prr;
+                    const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 64 + (((2 * u) ^ (pr & 15)) << 2));
+                    const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 64 + (((2 * u + 1) ^ (pr & 15)) << 2));
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pk[k] = pack2_bf16(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
+                    if (!(p.debug & 2) || pk[0] == 0x12345678u) *reinterpret_cast<uint4*>(Yb + goff(cp, q, it)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+            }
+        stamp(10);
+        return;
+    }
     // ================================================================ phase C: y = relu(Wc t2 + bc + x), two channel halves
     {
         float* stg = reinterpret_cast<float*>(lds + wave_scratch(wave));
@@ -432,7 +545,8 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
 }
 
 bool bneck_fusable(const BneckArgs& a) {
-    return a.Cin == 256 && a.Cmid == 64 && a.H % BT == 0 && a.W % BT == 0 && a.H == a.W &&
+    const bool shape = (a.Cin == 256 && !a.wd) || (a.Cin == 64 && a.wd && a.bd);
+    return shape && a.Cmid == 64 && a.H % BT == 0 && a.W % BT == 0 && a.H == a.W &&
            (size_t)a.B * a.H * a.W * 512 < ((size_t)1 << 32);      // 32-bit byte offsets in the store pass
 }
 
@@ -441,10 +555,11 @@ void launch_bneck(const BneckArgs& a_in, hipStream_t st) {
     a.debug = tune_get("BDBG", 0);
     a.stagger = tune_get("STAGGER", 0);
     ConvArgs d{};
-    d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
+    d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.wd ? nullptr : a.x;
     void* tok = prof_begin(d, 2, st);
     const int grid = a.B * (a.H / BT) * (a.W / BT);
-    hipLaunchKernelGGL((bneck64_kernel<256>), dim3(grid), dim3(512), 0, st, a);
+    if (a.wd) hipLaunchKernelGGL((bneck64_kernel<64, true>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((bneck64_kernel<256, false>), dim3(grid), dim3(512), 0, st, a);
     prof_end(tok, st);
 }
 
@@ -453,12 +568,12 @@ void launch_bneck(const BneckArgs& a_in, hipStream_t st) {
 // Tuning probe (not part of the reference surface): one fused bottleneck launch on caller-provided tensors with
 // s_memtime stamps at the phase boundaries of every workgroup: ts [B*(H/16)*(W/16)][16] uint64 (device).
 extern "C" int ivosw_bneck_probe(const void* x, void* y, const void* wa, const float* ba, const void* wb, const float* bb,
-                                 const void* wc, const float* bc, const void* zeros, int B, int H, int W, int Cin, int Cmid,
+                                 const void* wc, const float* bc, const void* wd, const float* bd, const void* zeros, int B, int H, int W, int Cin, int Cmid,
                                  unsigned long long* ts, ivosw_stream_t stream) {
     using namespace ivosw;
     IVOSW_REQUIRE(x && y && wa && ba && wb && bb && wc && bc && zeros, "null pointer");
     BneckArgs a{};
-    a.x = x; a.y = y; a.wa = wa; a.ba = ba; a.wb = wb; a.bb = bb; a.wc = wc; a.bc = bc; a.zeros = zeros;
+    a.x = x; a.y = y; a.wa = wa; a.ba = ba; a.wb = wb; a.bb = bb; a.wc = wc; a.bc = bc; a.wd = wd; a.bd = bd; a.zeros = zeros;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cmid = Cmid; a.ts = ts;
     IVOSW_REQUIRE(bneck_fusable(a), "shape is not covered by the fused bottleneck kernels");
     launch_bneck(a, as_stream(stream));

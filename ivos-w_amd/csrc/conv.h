@@ -25,6 +25,7 @@ struct BneckArgs {
     const void* wa; const float* ba;   // [Cmid][Cin]      packed as by launch_pack_conv
     const void* wb; const float* bb;   // [Cmid][9*Cmid]
     const void* wc; const float* bc;   // [4*Cmid][Cmid]
+    const void* wd; const float* bd;   // downsample [4*Cmid][Cin] (first block of a stage, stride 1) or null: identity residual
     const void* zeros;   // >= 256 B of device zeros
     int B, H, W, Cin, Cmid;
     unsigned long long* ts;  // optional [grid][16] s_memtime stamps at the phase boundaries (ivosw_bneck_probe), else null

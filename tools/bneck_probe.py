@@ -26,6 +26,9 @@ wa = (torch.randn(Cm, Cin, device=dev, generator=g) / Cin ** 0.5).to(torch.bfloa
 wb = (torch.randn(Cm, 9 * Cm, device=dev, generator=g) / (9 * Cm) ** 0.5).to(torch.bfloat16)
 wc = (torch.randn(4 * Cm, Cm, device=dev, generator=g) / Cm ** 0.5).to(torch.bfloat16)
 ba, bb, bc = (torch.randn(n, device=dev, generator=g) * 0.1 for n in (Cm, Cm, 4 * Cm))
+DS = Cin != 4 * Cm
+wd = (torch.randn(4 * Cm, Cin, device=dev, generator=g) / Cin ** 0.5).to(torch.bfloat16) if DS else None
+bd = torch.randn(4 * Cm, device=dev, generator=g) * 0.1 if DS else None
 zeros = torch.zeros(256, device=dev, dtype=torch.uint8)
 nwg = B * (H // 16) ** 2
 ts = torch.zeros(nwg, 16, device=dev, dtype=torch.int64)
@@ -34,7 +37,7 @@ st = L.stream_ptr(dev)
 
 def run(tsbuf):
     L.check(lib.ivosw_bneck_probe(L.dptr(x), L.dptr(y), L.dptr(wa), L.dptr(ba), L.dptr(wb), L.dptr(bb), L.dptr(wc), L.dptr(bc),
-                                  L.dptr(zeros), B, H, H, Cin, Cm, L.dptr(tsbuf) if tsbuf is not None else None, st), "probe")
+                                  L.dptr(wd) if DS else None, L.dptr(bd) if DS else None, L.dptr(zeros), B, H, H, Cin, Cm, L.dptr(tsbuf) if tsbuf is not None else None, st), "probe")
 
 
 for _ in range(3):
@@ -69,7 +72,8 @@ xf = x[:2].float().permute(0, 3, 1, 2)
 t1 = torch.relu(torch.nn.functional.conv2d(xf, wa.float()[:, :, None, None], ba)).to(torch.bfloat16).float()
 wb4 = wb.float().view(Cm, 3, 3, Cm).permute(0, 3, 1, 2)
 t2 = torch.relu(torch.nn.functional.conv2d(t1, wb4, bb, padding=1)).to(torch.bfloat16).float()
-ref = torch.relu(torch.nn.functional.conv2d(t2, wc.float()[:, :, None, None], bc) + xf).permute(0, 2, 3, 1)
+idt = torch.nn.functional.conv2d(xf, wd.float()[:, :, None, None], bd) if DS else xf
+ref = torch.relu(torch.nn.functional.conv2d(t2, wc.float()[:, :, None, None], bc) + idt).permute(0, 2, 3, 1)
 if dbg == 0:
     err = (y[:2].float() - ref).abs().max().item() / ref.abs().max().item()
     print(f"max rel err vs torch fp32-accumulate reference (bf16 intermediates): {err:.2e}")
