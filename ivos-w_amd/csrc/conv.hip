@@ -520,7 +520,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
 
     // ================= compute wave =================
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    constexpr bool PRE = (ES == 2);
+    constexpr bool PRE = (ES == 2) && (NW + LW) <= 12;   // 16-wave variant: 128 VGPRs per wave, no room for the residual tile
     constexpr int ITEMS = (BM * (BN / 8)) / (NW * 64);
     uint4 rres[PRE ? ITEMS : 1];
     if constexpr (PRE) {
@@ -614,7 +614,10 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
             const int grid = ((M + 255) / 256) * (a.Cout / 128);
             static const int tune_nk = getenv("IVOSW_TUNE_NK") ? atoi(getenv("IVOSW_TUNE_NK")) : 8;
             static const int use_ws = getenv("IVOSW_TUNE_WS") ? atoi(getenv("IVOSW_TUNE_WS")) : 1;
-            if (nk > tune_nk && use_ws) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 4>), dim3(grid), dim3(768), 0, st, a);
+            const int lw = tune_get("LW", 8);
+
+            if (nk > tune_nk && use_ws && lw == 8) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 8>), dim3(grid), dim3(1024), 0, st, a);
+            else if (nk > tune_nk && use_ws) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 4>), dim3(grid), dim3(768), 0, st, a);
             else if (nk > tune_nk) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
             else {  // K <= 128: bound by the output/residual stream -> 128x128 tiles, 64 KB LDS, 2 workgroups per CU
                 const int g2 = ((M + 127) / 128) * (a.Cout / 128);

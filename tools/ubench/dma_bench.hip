@@ -19,7 +19,7 @@ __global__ __launch_bounds__(1024) void fill_kernel(const char* src, size_t foot
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     // block-private slice of the footprint so that different CUs read different lines
     const size_t slice = footprint / gridDim.x;
-    const char* base = src + (size_t)blockIdx.x * slice;
+    const char* base = src + ((mode & 16) ? (size_t)0 : (mode & 32) ? (size_t)(blockIdx.x & 7) * slice : (size_t)blockIdx.x * slice);   // 16: every CU reads the same slice; 32: one slice per XCD
     const size_t wave_span = slice / nw;
     const char* wb = base + (size_t)wave * wave_span;
     const int row = lane >> 3;
@@ -76,12 +76,12 @@ int main() {
     hipMalloc(&sink, 64);
     hipMemset(src, 1, cap);
     printf("%-5s %-6s %-9s %-7s %-6s %10s %12s\n", "kind", "waves", "footprint", "stride", "depth", "GB/s", "B/clk/CU@2.1");
-    // (3) source-side details of the conv loaders: XOR-swizzled chunk order (1), shared-address dummy every 6th DMA (2), 1/8 zero rows (4)
-    for (int mode : {0, 8, 9})
-        for (int depth12 : {0, 1}) {
-            const size_t fp_l2 = (size_t)256 * 64 * 1024 * 4;
-            double a = depth12 ? run<12, true>(src, fp_l2, 512, 8, 300, sink, 256, mode) : run<6, true>(src, fp_l2, 512, 8, 600, sink, 256, mode);
-            printf("mode %d depth %-2d stride 512 L2-resident: %8.0f GB/s %6.1f B/clk/CU\n", mode, depth12 ? 12 : 6, a, a / 256 / 2.1);
+    // (4) sharing: every CU streams its own slice (0) / all CUs the same slice (16) / one slice per XCD (32); row stride 512 and 8192
+    for (int stride : {512, 8192})
+        for (int mode : {0, 16, 32}) {
+            const size_t fp = (size_t)256 * 64 * 1024 * (stride / 128);
+            double a = fp <= cap ? run<8, true>(src, fp, stride, 8, 400, sink, 256, mode) : 0;
+            printf("stride %-5d share-mode %-2d L2-resident: %8.0f GB/s %6.1f B/clk/CU\n", stride, mode, a, a / 256 / 2.1);
         }
     return 0;
 }
