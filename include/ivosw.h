@@ -106,20 +106,20 @@ size_t ivosw_assess_packed_bytes(int dtype);
 int ivosw_assess_pack(void* packed, int dtype, const void* const* tensors, int ntensors,
                       ivosw_stream_t stream);
 /* Replaces AssessNet.forward (models/assessment.py:164-182): tf [B,3,H,W], tp [B,H,W] fp32 ->
- * scores [B] fp32.  Frames are processed in chunks of `chunk` (<=0: library default) so that
- * layer-to-layer activations stay in the 256 MiB Infinity Cache.
+ * scores [B] fp32.  Frames are processed in chunks of `chunk` frames at res2, doubling per stage
+ * (<=0: library default, 256 bf16 / 16 fp32); the chunk bounds the workspace (ivosw_assess_ws_bytes).
  * tap_stage/tap_out (debug, tests): 0 = none; 1 roi[.,256,256,4] 2 stem[.,128,128,64] 3 pool[.,64,64,64]
  * 4..7 res2..res5 outputs, NHWC in `dtype`; 8 pooled [.,2048] fp32.  Only with B <= chunk.        */
 size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk);
 int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp,
                          int B, int H, int W, float* scores, void* ws, size_t ws_bytes, int chunk,
                          int tap_stage, void* tap_out, ivosw_stream_t stream);
-/* Name of the dominant kernel of the last ivosw_assess_forward configuration (for profiling).     */
+/* Kernel-name patterns of the dominant kernel family (the tower's contraction kernels) for profiling. */
 const char* ivosw_assess_dominant_kernel(int dtype);
 
 /* ------------------------------------------------------------------ measurement hooks ---------- */
 /* Not part of the reference surface: bench.py's roofline leg.  Between start and stop every launch of
- * the dominant kernel family (conv_igemm_kernel) is bracketed by hipEvents on the launch stream; stop
+ * the dominant kernel family (conv_igemm*, bneck64*) is bracketed by hipEvents on the launch stream; stop
  * synchronises those events and returns the summed kernel time (ms) and the launch count.          */
 int ivosw_profile_start(void);
 int ivosw_profile_stop(double* total_ms, int* launches);

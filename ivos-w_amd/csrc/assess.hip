@@ -1,9 +1,11 @@
 // AssessNet.forward on the MI355X: plan of the 54-conv tower, weight packing, chunked execution.
 //
 // Reference: AssessNet.forward (models/assessment.py:164-182), Encoder (:12-63), torchvision ResNet-50 v1.5.
-// Frames run through the whole tower in chunks (default 64 bf16 / 16 fp32) so that the layer-to-layer
-// activations of a chunk (<= ~2 MB per frame per tensor) stay resident in the 256 MiB Infinity Cache instead
-// of making a round trip to HBM between every pair of layers.
+// Frames run through the tower in chunks (default 256 bf16 / 16 fp32 frames at res2, doubling per stage).  Chunks
+// bound the workspace; they are NOT a cache-residency device: an Infinity-Cache-sized working set streams at
+// ~7 TB/s against ~6 TB/s from HBM (tools/ubench/dma_bench), while small launches cost occupancy, so the bf16
+// default is as large as the benchmark batch.  In bf16 mode the stride-1 bottlenecks of res2 run as ONE fused kernel
+// each (bottleneck.hip); everything else is layer by layer (conv.hip).
 #include <algorithm>
 #include <vector>
 
@@ -89,9 +91,9 @@ constexpr size_t E_ROI = 256 * 256 * 4, E_BIG = 64 * 64 * 256;
 constexpr size_t E_OUT[4] = {64 * 64 * 256, 32 * 32 * 512, 16 * 16 * 1024, 8 * 8 * 2048};
 
 // Chunk schedule.  Stage s (res2..res5) runs on c0 * 2^s frames at a time: every stage halves H and W and
-// doubles C, so doubling the frames per launch keeps the per-stage working set constant (c0 * 2 MB bf16 per
-// tensor: Infinity-Cache resident) while every conv launch still has >= 512 workgroups for the 256 CUs.
-static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 64 : 16; }
+// doubles C, so doubling the frames per launch keeps the per-stage tensor size constant (c0 * 2 MB bf16) and every
+// conv launch keeps >= 512 workgroups for the 256 CUs.
+static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 256 : 16; }
 
 struct Bufs {
     float* yxhw; int32_t* box; float* pooled;
@@ -163,8 +165,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
-    (void)dtype;
-    return "conv_igemm";
+    return dtype == IVOSW_BF16 ? "conv_igemm*|bneck64*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
 extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp, int B, int H, int W,

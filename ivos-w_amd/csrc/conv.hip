@@ -15,6 +15,7 @@
 // global stores (and residual loads) are full 16-B-per-lane row segments.
 #include <stdlib.h>
 
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -548,6 +549,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (p.debug & 8) continue;                   // ablation: loaders + barriers only (pure fill rate of the real access pattern)
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
         u32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int ks, int buf) {
