@@ -13,8 +13,9 @@ The same JSON line also carries, as `dqn`, the second half of BASELINE's metric:
 3 forwards + loss + BPTT -> [RCCL all-reduce of the 724 KB gradient arena when N>1] -> clamp+Adam ->
 target-sync coin flip).  `--workload dqn` makes that the headline `value` instead.
 
-roofline: dominant kernel = conv_igemm_kernel (bound: bf16 MFMA, 2.5 PFLOP/s dense).  achieved = algorithmic
-conv FLOPs per launch / average launch duration, timed with HIP events on the launch stream inside the library
+roofline: dominant kernel family = the tower's contraction kernels, conv_igemm* (layer by layer) and bneck64* (whole
+res2 bottlenecks fused) (bound: bf16 MFMA, 2.5 PFLOP/s dense).  achieved = algorithmic conv FLOPs per launch /
+average launch duration, timed with HIP events on the launch stream inside the library
 (ivosw_profile_start/stop) over extra steps that run right after the timed region, so the events do not perturb
 `value`.  cpu_baseline: the oracle (torch-CPU restatement of the reference path, kind "port") on a bounded
 sample, rank 0, N=1 only.
@@ -130,13 +131,19 @@ def bench_assess(args, rank, world, dev, dist):
     flops_step = GFLOP_PER_FRAME * 1e9 * args.batch
     achieved = flops_step / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")   # written from rocprofv3 --pmc passes of this command
-    if os.path.exists(tpath) and args.batch == 256 and args.precision == "bf16":
+    # HBM bytes per launch of the same kernel family: from the committed rocprofv3 --pmc passes of this very command
+    # (tools/profile_round.sh -> profiles/pmc_traffic_latest.json); only quoted when the launch count still matches
+    traffic, traffic_src, hbm_gbps = None, None, None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+    if os.path.exists(tpath) and args.batch == 256 and args.precision == "bf16" and not args.chunk:
         tj = json.load(open(tpath))
-        traffic, traffic_src = tj.get("bytes_per_launch"), tj.get("source")
-    roof = {"bound": "mfma", "kernel": lib.ivosw_assess_dominant_kernel(0).decode(), "achieved": round(achieved, 2),
+        if abs(tj.get("launches_per_pass", -1) - launches) < 0.5:
+            traffic, traffic_src = round(tj["bytes_per_launch"]), tj.get("source")
+            hbm_gbps = round(tj["bytes_per_pass"] / (conv_ms * 1e-3) / 1e9, 1)
+    dt_code = L.BF16 if args.precision == "bf16" else L.F32
+    roof = {"bound": "mfma", "kernel": lib.ivosw_assess_dominant_kernel(dt_code).decode(), "achieved": round(achieved, 2),
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_GBps_of_family": hbm_gbps, "hbm_peak_GBps": 8000.0,
             "launches_per_step": launches, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
             "flops_per_launch": flops_step / max(launches, 1), "kernel_ms_per_step": round(conv_ms, 3)}
     return fps, dt, roof

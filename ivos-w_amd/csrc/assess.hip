@@ -261,14 +261,18 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                     launch_roi_sample(tf + (size_t)f0 * 3 * plane, tp + (size_t)f0 * plane, bf.yxhw + (size_t)f0 * 4, nb, H, W,
                                       dtype, nrm, bf.roi, st);
                     tap(1, bf.roi, nb * E_ROI * es);
-                    // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool
-                    ConvArgs a{};
-                    a.zeros = base + P.zero_off; a.x = bf.roi; a.w = base + P.stem_w_off; a.bias = reinterpret_cast<const float*>(base + P.stem_b_off);
-                    a.res = nullptr; a.y = bf.stem; a.B = nb; a.H = 256; a.W = 256; a.Cin = 4; a.Ho = 128; a.Wo = 128;
-                    a.Cout = 64; a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
-                    launch_conv(a, dtype, true, st);
-                    tap(2, bf.stem, (size_t)nb * 128 * 128 * 64 * es);
-                    launch_maxpool(bf.stem, nb, 128, 128, 64, dtype, bf.pa, st);
+                    // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool (bf16: one fused kernel unless the stem tap is wanted)
+                    if (dtype == IVOSW_BF16 && tap_stage != 2 && tune_get("FUSE_STEM", 1)) {
+                        launch_stem_pool(bf.roi, base + P.stem_w_off, reinterpret_cast<const float*>(base + P.stem_b_off), nb, bf.pa, st);
+                    } else {
+                        ConvArgs a{};
+                        a.zeros = base + P.zero_off; a.x = bf.roi; a.w = base + P.stem_w_off; a.bias = reinterpret_cast<const float*>(base + P.stem_b_off);
+                        a.res = nullptr; a.y = bf.stem; a.B = nb; a.H = 256; a.W = 256; a.Cin = 4; a.Ho = 128; a.Wo = 128;
+                        a.Cout = 64; a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3; a.relu = 1;
+                        launch_conv(a, dtype, true, st);
+                        tap(2, bf.stem, (size_t)nb * 128 * 128 * 64 * es);
+                        launch_maxpool(bf.stem, nb, 128, 128, 64, dtype, bf.pa, st);
+                    }
                     tap(3, bf.pa, (size_t)nb * 64 * 64 * 64 * es);
                     char* o2 = bf.in[0] + (size_t)(f0 - f1) * E_OUT[0] * es;
                     run_stage(0, bf.pa, nb, o2);

@@ -1,0 +1,181 @@
+// Fused stem of the assessment encoder (bf16 throughput mode): 7x7/2 convolution over the 4-channel ROI tile
+// (R,G,B normalised | P), folded BN, ReLU and the 3x3/2 max-pool in ONE kernel.
+//
+// Reference arithmetic: Encoder.forward, models/assessment.py:54-57
+//     x = conv1(f) + conv1_p(p);  x = bn1(x);  c1 = relu(x);  x = maxpool(c1)
+// (conv1 | conv1_p are concatenated along Cin and the BN scale is folded into the weights by pack_stem_kernel).
+//
+// Why: layer by layer the 128x128x64 stem output (2 MB per frame in bf16) is written to HBM and read back by the
+// pool, and the generic implicit-GEMM kernel spends most of its time gathering 8-byte pixels (225 TFLOP/s).  Here a
+// workgroup owns an 8x8 tile of POOLED outputs: the 39x39-pixel input patch (12 KB) and the whole 64x7x8x4 filter
+// bank (28 KB) sit in LDS, im2col is pure fragment addressing (a lane's 8 K-elements = 2 neighbouring pixels x 4
+// channels = 16 contiguous bytes of the patch), the 17x17 conv outputs the tile needs go to LDS as bf16 and are
+// pooled from there.  Only the ROI tile comes in (0.5 MB per frame) and the pooled map goes out (0.5 MB per frame).
+//
+// MFMA view ("transposed": A = filters, B = pixels, so a lane holds 4 consecutive channels of one pixel):
+//   channels 64 = 2 tiles, conv pixels 289 -> 10 tiles of 32, K = 7 filter rows x 8 taps x 4 channels = 14 steps of 16
+//   (tap 7 of every filter row carries zero weights; the patch has a 40th zero column for it).
+#include "conv.h"
+#include "mfma_tile.h"
+
+namespace ivosw {
+
+namespace {
+constexpr int PT = 8;                         // pooled tile edge
+constexpr int CT = 2 * PT + 1;                // 17 conv outputs per edge
+constexpr int NPIX = CT * CT;                 // 289
+constexpr int PR = 2 * (CT - 1) + 7;          // 39 input rows / cols
+constexpr int PW = 40;                        // patch row stride in pixels (col 39 = zeros for the padding tap)
+constexpr int PATCH_OFF = 0, PATCH_BYTES = 12544;           // 39 * 320 = 12480, padded
+constexpr int WL_OFF = PATCH_OFF + PATCH_BYTES, WL_BYTES = 7 * 4 * 64 * 16;   // 28672
+constexpr int CO_OFF = WL_OFF + WL_BYTES, CO_BYTES = NPIX * 128;             // 36992
+constexpr int STEM_LDS = CO_OFF + CO_BYTES;                                   // 78208: two workgroups per CU
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+}  // namespace
+
+// Persistent: each workgroup loads the filter bank once and walks over tiles (tile id = first + k * stride); the next
+// tile's input patch is fetched into registers while the current tile is in the matrix cores.
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restrict__ roi, const bf16_t* __restrict__ wpk,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STEM_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, kh = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    // workgroups of one XCD (blockIdx % 8) take neighbouring tiles, so the 7-pixel halos are shared in that XCD's L2
+    const int per_xcd = gridDim.x >> 3;
+    const int first = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+
+    // patch entry j of this thread: pixel (r, c) of the 39 x 40 patch
+    constexpr int NPRE = (PR * PW + 255) / 256;   // 7
+    int pr_[NPRE], pc_[NPRE];
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int i = tid + 256 * j;
+        pr_[j] = i / PW;
+        pc_[j] = i - pr_[j] * PW;
+    }
+    uint2 pre[NPRE];
+    auto patch_fetch = [&](int t) {              // tile t -> registers (zero outside the 256 x 256 ROI tile and in col 39)
+        const int b = t >> 6, tl = t & 63;
+        const bf16_t* img = roi + (size_t)b * 256 * 256 * 4;
+        const int iy0 = 4 * (tl >> 3) * PT - 5, ix0 = 4 * (tl & 7) * PT - 5;
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int iy = iy0 + pr_[j], ix = ix0 + pc_[j];
+            const bool ok = pr_[j] < PR && pc_[j] < PR && iy >= 0 && iy < 256 && ix >= 0 && ix < 256;
+            const uint2* src = reinterpret_cast<const uint2*>(ok ? img + ((size_t)iy * 256 + ix) * 4 : wpk);   // always a valid address
+            const uint2 v = *src;
+            pre[j] = ok ? v : make_uint2(0, 0);
+        }
+    };
+    auto patch_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j)
+            if (tid + 256 * j < PR * PW) *reinterpret_cast<uint2*>(lds + PATCH_OFF + (tid + 256 * j) * 8) = pre[j];
+    };
+
+    int t = first;
+    if (t < ntiles) patch_fetch(t);
+    // filters: packed [64 ch][8 ky][8 taps][4] -> LDS [ky][tap pair q][ch][16 B] (consecutive channels 16 B apart)
+    for (int i = tid; i < 7 * 4 * 64; i += 256) {
+        const int ch = i & 63, kq = i >> 6, ky = kq >> 2, q = kq & 3;
+        *reinterpret_cast<uint4*>(lds + WL_OFF + i * 16) = *reinterpret_cast<const uint4*>(wpk + ((ch * 8 + ky) * 8 + 2 * q) * 4);
+    }
+    const int ct = wave & 1, pq = wave >> 1;      // conv: wave = (channel tile ct, pixel tiles pq, pq+2, .., pq+8)
+    unsigned pb[5];                               // LDS address of this lane's pixel pair at (ky, tap half) = (0, 0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int p = min((pq + 2 * i) * 32 + lrow, NPIX - 1);
+        const int cy = p / CT, cx = p - cy * CT;
+        pb[i] = lds_base + PATCH_OFF + ((2 * cy) * PW + 2 * cx + 2 * kh) * 8;
+    }
+    const unsigned wb = lds_base + WL_OFF + (kh * 64 + ct * 32 + lrow) * 16;
+    float4 bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bias + ct * 32 + 8 * g + 4 * kh);
+
+    for (; t < ntiles; t += gridDim.x) {
+        const int b = t >> 6, tl = t & 63;
+        const int py0 = (tl >> 3) * PT, px0 = (tl & 7) * PT;
+        patch_store();                            // (the previous tile's pooling is behind the barrier at the loop end)
+        __syncthreads();
+        asm volatile("" ::: "memory");
+        if (t + (int)gridDim.x < ntiles) patch_fetch(t + gridDim.x);   // in flight under the MFMAs
+
+        f32x16 acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        {
+            u32x4 wf[2], pf[2][5];
+            auto frag_read = [&](int s, int buf) {       // step s: filter row s >> 1, taps 4*(s&1) .. +3
+                const int ky = s >> 1, h2 = s & 1;
+                wf[buf] = lds_read_b128(wb + ((ky * 4 + 2 * h2) * 64) * 16);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) pf[buf][i] = lds_read_b128(pb[i] + ky * (PW * 8) + h2 * 32);
+            };
+            frag_read(0, 0);
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                lds_wait();
+                if (s < 13) frag_read(s + 1, (s + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) acc[i] = mfma_bf16(wf[s & 1], pf[s & 1][i], acc[i]);
+            }
+        }
+        // + bias, ReLU, zero outside the 128x128 conv map (pool padding: every window holds a valid value >= 0)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int p = (pq + 2 * i) * 32 + lrow;
+            if (p < NPIX) {
+                const int cyl = p / CT, cxl = p - cyl * CT;
+                const int cy = 2 * py0 - 1 + cyl, cx = 2 * px0 - 1 + cxl;
+                const bool in = cy >= 0 && cy < 128 && cx >= 0 && cx < 128;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v0 = fmaxf(acc[i][4 * g] + bq[g].x, 0.f), v1 = fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f);
+                    const float v2 = fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), v3 = fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f);
+                    uint2 pk;
+                    pk.x = in ? pack2_bf16(v0, v1) : 0u;
+                    pk.y = in ? pack2_bf16(v2, v3) : 0u;
+                    *reinterpret_cast<uint2*>(lds + CO_OFF + p * 128 + (((ct * 4 + g) ^ (p & 7)) << 4) + 8 * kh) = pk;
+                }
+            }
+        }
+        __syncthreads();                          // conv tile complete; every wave is done reading the patch
+        // 3x3/2 max-pool out of LDS; non-negative bf16 order like their bit patterns: packed u16 max
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = it * 256 + tid;
+            const int pp = item >> 3, cg = item & 7;
+            const int ppy = pp >> 3, ppx = pp & 7;
+            u16x8 m = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int p = (2 * ppy + dy) * CT + 2 * ppx + dx;
+                    const u16x8 v = *reinterpret_cast<const u16x8*>(lds + CO_OFF + p * 128 + ((cg ^ (p & 7)) << 4));
+                    m = __builtin_elementwise_max(m, v);
+                }
+            *reinterpret_cast<u16x8*>(out + (((size_t)b * 64 + py0 + ppy) * 64 + px0 + ppx) * 64 + cg * 8) = m;
+        }
+        // the next iteration's patch_store only touches the patch (free since the barrier above); its epilogue writes
+        // the conv tile after ITS first barrier, which every wave reaches only after finishing this pooling pass
+    }
+}
+
+void launch_stem_pool(const void* roi, const void* w, const float* bias, int B, void* out, hipStream_t st) {
+    ConvArgs d{};
+    d.B = B; d.H = 256; d.W = 256; d.Cin = 4; d.Ho = 128; d.Wo = 128; d.Cout = 64; d.KH = 7; d.KW = 7; d.stride = 2;
+    void* tok = prof_begin(d, 2, st);
+    const int ntiles = B * 64;
+    const int grid = ntiles < 512 ? ntiles : 512;             // 2 workgroups per CU (78 KB of LDS each), persistent over the tiles
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(roi), static_cast<const bf16_t*>(w),
+                       bias, static_cast<bf16_t*>(out), ntiles);
+    prof_end(tok, st);
+}
+
+}  // namespace ivosw

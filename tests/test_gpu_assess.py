@@ -140,6 +140,29 @@ def test_fused_bottleneck_matches_layerwise(dev, net16, net32):
         lib.ivosw_tune_set(b"FUSE", 1)
 
 
+def test_fused_stem_pool_matches_layerwise(dev, net16):
+    """bf16 mode: stem conv + BN + ReLU + max-pool in one kernel (tunable FUSE_STEM=1, default) against the conv and
+    pool kernels run separately: same bf16 operands, fp32 accumulation, one bf16 rounding before the (exact) max."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge in ((8, True), (3, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        try:
+            lib.ivosw_tune_set(b"FUSE_STEM", 1)
+            _, a = net16.forward_tap(ttf, ttp, "pool")
+            lib.ivosw_tune_set(b"FUSE_STEM", 0)
+            _, b = net16.forward_tap(ttf, ttp, "pool")
+        finally:
+            lib.ivosw_tune_set(b"FUSE_STEM", 1)
+        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+        assert a.shape == (B, 64, 64, 64) and (a >= 0).all()
+        scale = np.abs(b).max()
+        # accumulation order differs (K = 224 vs the generic kernel's 256-padded K tiles): a bf16 ulp on a few elements
+        assert np.abs(a - b).max() <= 2 ** -7 * scale, np.abs(a - b).max() / scale
+        assert np.mean(a != b) < 0.02
+        np.testing.assert_allclose(a.mean(), b.mean(), rtol=1e-4)
+
+
 def test_full_size_properties(dev, net16, net32):
     """B=64 at 480p: results are independent of batch composition/chunking (each frame is an independent unit),
     and the bf16 path ranks frames like the fp32 path up to its own noise."""

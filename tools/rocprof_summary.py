@@ -14,7 +14,8 @@ def demangle(n):
 
 
 def main():
-    db, fam = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "conv_igemm_kernel")
+    db, fam = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "conv_igemm|bneck64")
+    like = " or ".join(f"s.kernel_name like '%{x}%'" for x in fam.split("|"))
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute(
         "select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start), "
@@ -30,7 +31,7 @@ def main():
     rows = list(cur.execute(
         "select s.kernel_name, d.grid_size_x, count(*), sum(d.end-d.start), avg(d.end-d.start) "
         "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
-        f"where s.kernel_name like '%{fam}%' group by s.kernel_name, d.grid_size_x order by 4 desc"))
+        f"where {like} group by s.kernel_name, d.grid_size_x order by 4 desc"))
     ft = sum(r[3] for r in rows)
     n = sum(r[2] for r in rows)
     print(f"# family total {ft/1e6:.3f} ms, {n} launches, avg {ft/max(n,1)/1e3:.2f} us\n")
