@@ -601,6 +601,212 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
     epilogue_store<T, BM, BN, NW * 64, PRE>(p, Cs, m0, n0, M, tid, rres);
 }
 
+// ---------------------------------------------------------------- 3x3 stride-1 convolution with an LDS-resident patch (bf16)
+// The implicit-GEMM kernels above fetch the A tile once per filter tap: 9 x 32 KB per 64-channel slice of a 256-pixel
+// tile, and the ~20 B/clk/CU fill path (L2 hits + DRAM misses retiring in order) is what bounds them.  Here the
+// halo patch of the tile (<= 400 pixels x 64 channels, 41-50 KB) is fetched ONCE per channel slice and all nine taps
+// read it through shifted fragment rows (output pixel m, tap (ky,kx) -> patch row hb(m) + ky*(TW+2) + kx); only the
+// 16-KB weight tiles stream per tap.  Fill bytes per tap drop from 48 KB to ~21 KB.
+//   tile = F frames x TH x TW output pixels (256), BN = 128 output channels, 8 compute + 8 loader waves
+//   LDS: two patch buffers (channel slices alternate) | 3-slot weight ring | epilogue tile aliases everything
+template <int F, int TH>
+__global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
+    typedef bf16_t T;
+    constexpr int TW = TH, HW2 = TW + 2, HP = (TH + 2) * HW2, HRT = F * HP;   // halo rows of the tile
+    constexpr int NG = (HRT + 7) / 8;                                          // 1-KB DMA row groups per patch
+    constexpr int PB = NG * 1024;
+    constexpr int NW = 8, LW = 8, TM = 2, TN = 2, BM = 256, BN = 128, KE = 64, CE = 8;
+    constexpr int WSLOT = BN * ROWB, WR = 3;
+    constexpr int W_OFF = 2 * PB;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int USED = W_OFF + WR * WSLOT;
+    constexpr int LDS_BYTES = USED > EPI_BYTES ? USED : EPI_BYTES;
+    static_assert(F * TH * TW == BM && LDS_BYTES <= 163840, "tile geometry / LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbn = p.Cout / BN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    // n-major (p.nmajor): the workgroups of one XCD share ONE 128-channel weight slice (its L2 keeps it: the weight
+    // tiles are ~85 % of the fill bytes here); m-major: the n-tiles of one pixel tile share its patch instead
+    const int nbm = gridDim.x / nbn;
+    const int tile_n = p.nmajor ? L / nbm : L % nbn, tile_m = p.nmajor ? L % nbm : L / nbn;
+    const int n0 = tile_n * BN;
+    const int tpf = (p.H / TH) * (p.W / TW);                 // tiles per frame (1 when a tile spans F whole frames)
+    const int b0 = (F > 1) ? tile_m * F : tile_m / tpf;
+    const int tl = (F > 1) ? 0 : tile_m % tpf;
+    const int y0 = (tl / (p.W / TW)) * TH, x0 = (tl % (p.W / TW)) * TW;
+    const int K = 9 * p.Cin;
+    const int nc = p.Cin / KE;                               // channel slices
+    const int nj = nc * 9;                                   // (slice, tap) steps
+
+    if (wave >= NW) {
+        // ================= loader wave =================
+        const int lw = wave - NW;
+        const T* X = static_cast<const T*>(p.x);
+        const T* Wt = static_cast<const T*>(p.w);
+        const T* zeros = static_cast<const T*>(p.zeros);
+        const int rsub = lane >> 3, cpos = lane & 7;
+        constexpr int MAXG = (NG + LW - 1) / LW;
+        const int np = (NG - lw + LW - 1) / LW;              // patch row groups of this wave: lw, lw+8, ...
+        const T* abase[MAXG];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) {
+            const int g = lw + LW * i;
+            const int hr = g * 8 + rsub;
+            const int f = hr / HP, rem = hr - f * HP;
+            const int hy = rem / HW2, hx = rem - hy * HW2;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NG && hr < HRT && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            abase[i] = ok ? X + (((long)(b0 + f) * p.H + y) * p.W + x) * p.Cin + (cpos ^ ((hr >> 1) & 7)) * CE : zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        const T* bsrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (lw * 2 + i) * 8 + rsub;
+            bsrc[i] = Wt + (long)(n0 + row) * K + (cpos ^ ((row >> 1) & 7)) * CE;
+        }
+        auto issue_patch = [&](int c) {
+            unsigned char* pbuf = lds + (c & 1) * PB;
+#pragma unroll
+            for (int i = 0; i < MAXG; ++i) {
+                const int g = lw + LW * i;
+                if (g < NG) dma16(abase[i] + (((okmask >> i) & 1u) ? c * KE : 0), pbuf + g * 1024);
+            }
+        };
+        auto issue_w = [&](int j) {                          // weight tile of step j = slice * 9 + tap
+            const int c = j / 9, t = j - c * 9;
+            unsigned char* sb = lds + W_OFF + (j % WR) * WSLOT;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma16(bsrc[i] + (long)t * p.Cin + c * KE, sb + (lw * 2 + i) * 1024);
+        };
+        // issue order: P0 W0 W1 | after barrier j: W(j+2); after barrier (c,3): P(c+1)
+        issue_patch(0);
+        issue_w(0);
+        if (nj > 1) issue_w(1);
+        for (int j = 0; j < nj; ++j) {
+            const int c = j / 9, t = j - c * 9;
+            // younger than W(j) at this point: W(j+1), and P(c+1) during taps 4 and 5 (issued behind W(c*9+5))
+            int younger = (j + 1 < nj) ? 2 : 0;
+            if ((t == 4 || t == 5) && c + 1 < nc) younger += np;
+            wait_vmcnt_n(younger);
+            __builtin_amdgcn_s_barrier();                    // step j: its weights (and patch) landed; step j-1 is done
+            if (j + 2 < nj) issue_w(j + 2);
+            if (t == 3 && c + 1 < nc) issue_patch(c + 1);    // patch buffer (c+1)&1 was last read in slice c-1
+        }
+        __builtin_amdgcn_s_barrier();                        // matches the two epilogue barriers of the compute waves
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ================= compute wave =================
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int hb[TM];                                              // patch row of this lane's output pixel at tap (0,0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 32 + lrow;
+        const int f = m / (TH * TW), rem = m - f * (TH * TW);
+        const int y = rem / TW, x = rem - y * TW;
+        hb[i] = f * HP + y * HW2 + x;
+    }
+    int c = 0, t = 0;
+    for (int j = 0; j < nj; ++j) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (p.debug & 8) continue;                           // ablation: loaders + barriers only
+        const unsigned a_base = lds_base + (c & 1) * PB, b_base = lds_base + W_OFF + (j % WR) * WSLOT;
+        const int ky = t / 3, kx = t - ky * 3;
+        unsigned arow[TM], asw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int hr = hb[i] + ky * HW2 + kx;
+            arow[i] = a_base + hr * ROWB;
+            asw[i] = (hr >> 1) & 7;
+        }
+        u32x4 fa[2][TM], fb[2][TN];
+        auto frag_read = [&](int ks, int buf) {
+            const int ch = 2 * ks + lhalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[buf][i] = lds_read_b128(arow[i] + ((ch ^ asw[i]) << 4));
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) fb[buf][jj] = lds_read_b128(b_base + swz((wn * TN + jj) * 32 + lrow, ch));
+        };
+        frag_read(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            lds_wait();
+            if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);
+            if (p.debug & 2) {                               // ablation: fragment reads without the MFMAs
+                asm volatile("" ::"v"(fa[ks & 1][0]), "v"(fa[ks & 1][1]), "v"(fb[ks & 1][0]), "v"(fb[ks & 1][1]));
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) acc[i][jj] = mfma_bf16(fa[ks & 1][i], fb[ks & 1][jj], acc[i][jj]);
+        }
+        if (++t == 9) { t = 0; ++c; }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const int col = (wn * TN + j) * 32 + lrow;
+                Cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    // rows of the tile are (frame, y, x) inside the tile: map them back to NHWC pixel indices for the store pass
+    ConvArgs q = p;
+    q.res = nullptr;
+    constexpr int CPR = BN / 8;
+    T* Y = static_cast<T*>(p.y);
+    const float4 bb0 = *reinterpret_cast<const float4*>(p.bias + n0 + (tid % CPR) * 8);
+    const float4 bb1 = *reinterpret_cast<const float4*>(p.bias + n0 + (tid % CPR) * 8 + 4);
+#pragma unroll
+    for (int it = 0; it < (BM * CPR) / (NW * 64); ++it) {
+        const int item = it * (NW * 64) + tid;
+        const int row = item / CPR, cg = item - row * CPR;
+        const int f = row / (TH * TW), rem = row - f * (TH * TW);
+        const int y = rem / TW, x = rem - y * TW;
+        const long o = ((((long)(b0 + f) * p.H + y0 + y) * p.W + x0 + x)) * p.Cout + n0 + cg * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+        float v[8] = {v0.x + bb0.x, v0.y + bb0.y, v0.z + bb0.z, v0.w + bb0.w, v1.x + bb1.x, v1.y + bb1.y, v1.z + bb1.z, v1.w + bb1.w};
+        uint32_t pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = v[2 * k], bq = v[2 * k + 1];
+            if (p.relu) { a = fmaxf(a, 0.f); bq = fmaxf(bq, 0.f); }
+            pk[k] = pack2_bf16(a, bq);
+        }
+        *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
+// shapes covered by conv3x3_patch_kernel
+static bool patch3x3_ok(const ConvArgs& a) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.res || a.H != a.W || a.Cin % 64 || a.Cout % 128) return false;
+    return (a.H == 32 || a.H == 16) || (a.H == 8 && a.B % 4 == 0);
+}
+
 template <typename T, bool STEM>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
     const int M = a.B * a.Ho * a.Wo;
@@ -616,6 +822,14 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
             const int grid = ((M + 255) / 256) * (a.Cout / 128);
             static const int tune_nk = getenv("IVOSW_TUNE_NK") ? atoi(getenv("IVOSW_TUNE_NK")) : 8;
             static const int use_ws = getenv("IVOSW_TUNE_WS") ? atoi(getenv("IVOSW_TUNE_WS")) : 1;
+            if constexpr (sizeof(T) == 2) {
+                if (patch3x3_ok(a) && tune_get("PATCH3", 1)) {
+                    const int g3 = (M / 256) * (a.Cout / 128);
+                    if (a.H == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 8>), dim3(g3), dim3(1024), 0, st, a);
+                    else hipLaunchKernelGGL((conv3x3_patch_kernel<1, 16>), dim3(g3), dim3(1024), 0, st, a);
+                    return;
+                }
+            }
             const int lw = tune_get("LW", 8);
 
             if (nk > tune_nk && use_ws && lw == 8) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 8>), dim3(grid), dim3(1024), 0, st, a);
@@ -672,7 +886,7 @@ void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
     ConvArgs a = a_in;
     a.debug = dbg;
     {
-        const int nm = tune_get("NMAJOR", 0);       // 0 off, 1 all ws launches, 2 only 3x3
+        const int nm = tune_get("NMAJOR", 0);       // 0 off, 1 all ws / patch launches, 2 only 3x3
         a.nmajor = (nm == 1) || (nm == 2 && a.KH == 3);
     }
     void* tok = prof_begin(a, (dtype == IVOSW_BF16) ? 2 : 4, st);
