@@ -41,7 +41,10 @@ def test_host_only_queries(handle):
     assert lib.ivosw_assess_packed_bytes(L.BF16) < lib.ivosw_assess_packed_bytes(L.F32)
     assert lib.ivosw_assess_packed_bytes(7) == 0
     assert lib.ivosw_assess_ws_bytes(L.BF16, 256, 480, 854, 0) > 0
-    assert lib.ivosw_assess_dominant_kernel(L.BF16).decode() == "conv_igemm"
+    fam = lib.ivosw_assess_dominant_kernel(L.BF16).decode().split("|")
+    assert "conv_igemm*" in fam and "bneck64*" in fam           # kernel-name patterns of the tower's contraction kernels
+    assert lib.ivosw_assess_dominant_kernel(L.F32).decode() == "conv_igemm*"
+    assert lib.ivosw_tune_set(b"FUSE", 1) == 0 and lib.ivosw_tune_set(None, 1) != 0
 
 
 def test_argument_errors_do_not_touch_the_gpu(handle):

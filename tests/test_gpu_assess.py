@@ -140,6 +140,38 @@ def test_fused_bottleneck_matches_layerwise(dev, net16, net32):
         lib.ivosw_tune_set(b"FUSE", 1)
 
 
+def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
+    """bf16 mode: the 3x3 stride-1 layers with the halo patch LDS-resident (tunable PATCH3=1, default) against the
+    per-tap implicit-GEMM kernel (PATCH3=0): same operands, same K order inside a tap, different accumulation order
+    across channel slices and taps -> bf16 ulps on the stage outputs, scores within the bf16 tolerance."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    _, _, ttf, ttp = inputs(dev, 8, True)      # B=8: res5 uses the 4-frame tile (B % 4 == 0)
+    try:
+        for nm in ("res3", "res4", "res5"):
+            lib.ivosw_tune_set(b"PATCH3", 1)
+            _, a = net16.forward_tap(ttf, ttp, nm)
+            lib.ivosw_tune_set(b"PATCH3", 0)
+            _, b = net16.forward_tap(ttf, ttp, nm)
+            a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+            scale = np.abs(b).max()
+            assert np.abs(a - b).max() <= 2e-2 * scale, (nm, np.abs(a - b).max() / scale)
+            np.testing.assert_allclose(a.mean(), b.mean(), rtol=2e-3, err_msg=nm)
+        lib.ivosw_tune_set(b"PATCH3", 1)
+        sa = net16(ttf, ttp).cpu().numpy()
+        lib.ivosw_tune_set(b"PATCH3", 0)
+        sb = net16(ttf, ttp).cpu().numpy()
+        np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
+        # B=3: res5's 4-frame tile does not apply (B % 4 != 0) -> the per-tap kernel serves it, results stay per-frame identical
+        _, _, t3f, t3p = inputs(dev, 3, False)
+        lib.ivosw_tune_set(b"PATCH3", 1)
+        s3 = net16(t3f, t3p).cpu().numpy()
+        np.testing.assert_allclose(s3.reshape(-1), np.load(os.path.join(os.path.dirname(__file__), "golden", "assess_forward.npz"))["B3_score"].reshape(-1),
+                                   rtol=BF16_SCORE_RTOL)
+    finally:
+        lib.ivosw_tune_set(b"PATCH3", 1)
+
+
 def test_fused_stem_pool_matches_layerwise(dev, net16):
     """bf16 mode: stem conv + BN + ReLU + max-pool in one kernel (tunable FUSE_STEM=1, default) against the conv and
     pool kernels run separately: same bf16 operands, fp32 accumulation, one bf16 rounding before the (exact) max."""
