@@ -460,7 +460,11 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
                     unsigned pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pk[k] = pack2_bf16(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
-                    if (!(p.debug & 2) || pk[0] == 0x12345678u) *reinterpret_cast<uint4*>(Yb + goff(cp, q, it)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    if (!(p.debug & 2) || pk[0] == 0x12345678u) {
+                        u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
+                        if (p.nt) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)));
+                        else *reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)) = ov;
+                    }
                 }
             }
         stamp(10);
@@ -536,7 +540,11 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
                         const float hi = fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f);
                         pk[k] = pack2_bf16(lo, hi);
                     }
-                    if (!(p.debug & 2) || pk[0] == 0x12345678u) *reinterpret_cast<uint4*>(Yb + goff(cp, q, it)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    if (!(p.debug & 2) || pk[0] == 0x12345678u) {
+                        u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
+                        if (p.nt) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)));
+                        else *reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)) = ov;
+                    }
                 }
             }
         }
@@ -554,6 +562,7 @@ void launch_bneck(const BneckArgs& a_in, hipStream_t st) {
     BneckArgs a = a_in;
     a.debug = tune_get("BDBG", 0);
     a.stagger = tune_get("STAGGER", 0);
+    a.nt = (tune_get("NT", 3) >> 2) & 1;   // bit 2: measured neutral-to-worse here (the next block re-reads y through L2)
     ConvArgs d{};
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.wd ? nullptr : a.x;
     void* tok = prof_begin(d, 2, st);

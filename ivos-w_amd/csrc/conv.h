@@ -13,6 +13,7 @@ struct ConvArgs {
     const void* zeros;  // >= 16 B of device zeros: source of the zero-padding taps for the LDS-DMA loader
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
     int nmajor;         // tile order of the wave-specialised kernel: 0 m-major, 1 n-major
+    int nt;             // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (generic epilogue), bit 2: also in the patch / fused kernels (tunable NT, default 3)
     int debug;          // ablation bits (IVOSW_DEBUG_CONV, tuning only): 1 skip epilogue stores, 2 skip MFMA, 4 skip DMA after the first tile
 };
 
@@ -29,6 +30,7 @@ struct BneckArgs {
     const void* zeros;   // >= 256 B of device zeros
     int B, H, W, Cin, Cmid;
     unsigned long long* ts;  // optional [grid][16] s_memtime stamps at the phase boundaries (ivosw_bneck_probe), else null
+    int nt;              // non-temporal y stores
     int stagger;         // > 0: odd first-round workgroups start stagger x 8128 cycles late (tunable STAGGER)
     int debug;           // ablation bits (tunable BDBG): 1 no residual read, 2 no stores, 4 K-tile 0 only (L2-hot A), 8 no MFMA
 };

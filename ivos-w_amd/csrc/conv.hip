@@ -53,7 +53,9 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
         if constexpr (ES == 2) {
             if (R) {
                 uint4 rr;
-                if constexpr (PRE) rr = pre[it]; else rr = *reinterpret_cast<const uint4*>(R + o);
+                if constexpr (PRE) rr = pre[it];
+                else if (p.nt & 2) { const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(R + o)); rr = make_uint4(t[0], t[1], t[2], t[3]); }
+                else rr = *reinterpret_cast<const uint4*>(R + o);
                 const uint32_t w4[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -68,7 +70,12 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
                 if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
                 pk[q] = pack2_bf16(a, b);
             }
-            *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (p.nt & 1) {
+                u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
+                __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Y + o));
+            } else {
+                *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
         } else {
             if (R) {
                 const float4 r0v = *reinterpret_cast<const float4*>(R + o);
@@ -347,7 +354,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
                 const int item = it * (NW * 64) + tid;
                 const int row = item / (BN / 8), cg = item - row * (BN / 8);
                 const int m = min(m0 + row, M - 1);   // clamp instead of branching: a predicated load would be waited for at once
-                rres[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.Cout + n0 + cg * 8);
+                if (p.nt & 2) { const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(R + (long)m * p.Cout + n0 + cg * 8)); rres[it] = make_uint4(t[0], t[1], t[2], t[3]); }
+                else rres[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.Cout + n0 + cg * 8);
             }
         }
     }
@@ -532,7 +540,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
                 const int item = it * (NW * 64) + tid;
                 const int row = item / (BN / 8), cg = item - row * (BN / 8);
                 const int m = min(m0 + row, M - 1);
-                rres[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.Cout + n0 + cg * 8);
+                if (p.nt & 2) { const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(R + (long)m * p.Cout + n0 + cg * 8)); rres[it] = make_uint4(t[0], t[1], t[2], t[3]); }
+                else rres[it] = *reinterpret_cast<const uint4*>(R + (long)m * p.Cout + n0 + cg * 8);
             }
         }
     }
@@ -797,7 +806,12 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
             if (p.relu) { a = fmaxf(a, 0.f); bq = fmaxf(bq, 0.f); }
             pk[k] = pack2_bf16(a, bq);
         }
-        *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        if (p.nt & 4) {                                       // bit 2 (off by default: measured slightly worse for this kernel)
+            u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Y + o));
+        } else {
+            *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
     }
 }
 
@@ -888,6 +902,7 @@ void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
     {
         const int nm = tune_get("NMAJOR", 0);       // 0 off, 1 all ws / patch launches, 2 only 3x3
         a.nmajor = (nm == 1) || (nm == 2 && a.KH == 3);
+        a.nt = tune_get("NT", 3);   // streaming tensors are far larger than L2: keep them from evicting the A / weight lines that ARE reused
     }
     void* tok = prof_begin(a, (dtype == IVOSW_BF16) ? 2 : 4, st);
     if (dtype == IVOSW_BF16) {
