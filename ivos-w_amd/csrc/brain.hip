@@ -44,9 +44,21 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     __shared__ float red[32][33];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + c;
-    float s = 0.f;
-    if (n < N)
-        for (int m = rg; m < M; m += 32) s += A[(size_t)m * ld + n];
+    // four independent partial sums and 8 loads in flight per thread: the loop is a chain of global-load latencies
+    // otherwise (M/32 = 100 dependent round trips, 15 us); the summation order stays fixed (deterministic)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < N) {
+        int m = rg;
+        for (; m + 224 < M; m += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = A[(size_t)(m + 32 * u) * ld + n];
+            s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+            s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+        }
+        for (; m < M; m += 32) s0 += A[(size_t)m * ld + n];
+    }
+    const float s = (s0 + s1) + (s2 + s3);
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && n < N) {

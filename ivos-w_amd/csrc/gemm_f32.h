@@ -1,7 +1,7 @@
 // Small-shape fp32 GEMM on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain).
 // Serves the Brain's batched (non-recurrent) contractions: encoder_fc2, the input-side LSTM gates,
 // decoder_fc1 and every dgrad / wgrad of the backward pass.  Shapes are tiny (M <= a few thousand,
-// N,K <= 512), so the tile is 64x64x16 with generic operand strides; wgrad shapes (small MxN, long K)
+// N,K <= 512), so the tile is 64x64x64 with generic operand strides; wgrad shapes (small MxN, long K)
 // use split-K into slabs + a fixed-order reduce (deterministic, no atomics).
 #pragma once
 #include "common.h"
@@ -24,7 +24,10 @@ struct GemmF32 {
     int splitk;          // gridDim.z
 };
 
-constexpr int GB_M = 64, GB_N = 64, GB_K = 16, G_LD = 65;
+// K-step 64: at these sizes a GEMM is a handful of dependent global-load round trips; 16-deep steps cost 8 of them for
+// K = 128 (18 us per launch), 64-deep steps 2 with 16 loads per operand and thread in flight
+constexpr int GB_M = 64, GB_N = 64, GB_K = 64, G_LD = 65;
+constexpr int G_NI = GB_M * GB_K / 256;   // elements per operand per thread per K-step
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 g) {
     __shared__ float As[GB_K][G_LD];
@@ -37,30 +40,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 g) {
     const int kend = min(g.K, kbeg + kchunk);
     const bool a_kfast = (g.sak == 1), b_kfast = (g.sbk == 1);
 
-    float ra[4], rb[4];
+    float ra[G_NI], rb[G_NI];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G_NI; ++i) {
             int m, k;
-            if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            if (a_kfast) { k = tid % GB_K; m = tid / GB_K + (256 / GB_K) * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
             const int gm = m0 + m, gk = k0 + k;
             float v = 0.f;
             if (gm < g.M && gk < kend) v = g.A[gm * g.sam + gk * g.sak];
             ra[i] = g.relu_a ? fmaxf(v, 0.f) : v;
             int n, kb;
-            if (b_kfast) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
+            if (b_kfast) { kb = tid % GB_K; n = tid / GB_K + (256 / GB_K) * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
             const int gn = n0 + n, gkb = k0 + kb;
             rb[i] = (gn < g.N && gkb < kend) ? g.B[gkb * g.sbk + gn * g.sbn] : 0.f;
         }
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G_NI; ++i) {
             int m, k;
-            if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            if (a_kfast) { k = tid % GB_K; m = tid / GB_K + (256 / GB_K) * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
             As[k][m] = ra[i];
             int n, kb;
-            if (b_kfast) { kb = tid & 15; n = (tid >> 4) + 16 * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
+            if (b_kfast) { kb = tid % GB_K; n = tid / GB_K + (256 / GB_K) * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
             Bs[kb][n] = rb[i];
         }
     };
