@@ -110,15 +110,32 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwd p) {
     const float gk = ((tid >> 7) == 2) ? 2.0f : 1.0f;
     const int Nk = p.N - p.keep_from;  // kept buffers are indexed by (sample - keep_from)
     const int row0 = blockIdx.x * R;
+    // the input-side gate term of the NEXT step is fetched while this step computes: its global-load latency sat at the
+    // head of every step's fma chain (the arithmetic order is unchanged: the chain still starts from that term)
+    float a_nx[R];
+    auto gx_fetch = [&](int s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = min(row0 + r, 2 * p.N - 1);
+            const int d = row / p.N, n = row - d * p.N;
+            const int t = d ? p.T - 1 - s : s;
+            a_nx[r] = p.gx[((size_t)n * p.T + t) * 512 + tid];
+        }
+    };
+    gx_fetch(0);
     for (int s = 0; s < p.T; ++s) {
-        // rows one at a time in a rolled loop: W_hh owns the register file, per-row state lives in LDS
-#pragma unroll 1
+        float a_cur[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a_cur[r] = a_nx[r];
+        if (s + 1 < p.T) gx_fetch(s + 1);
+        // rows one at a time: W_hh owns the register file, per-row state lives in LDS
+#pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r;
             if (row >= 2 * p.N) break;
             const int d = row / p.N, n = row - d * p.N;
             const int t = d ? p.T - 1 - s : s;
-            float a = p.gx[((size_t)n * p.T + t) * 512 + tid];
+            float a = a_cur[r];
             // h == 0 at s == 0, so the first step needs no special case (fma(0,w,a) == a)
 #pragma unroll
             for (int kc = 0; kc < HD / 4; ++kc) {
