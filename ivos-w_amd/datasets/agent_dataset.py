@@ -22,33 +22,55 @@ class DAVIS2017AgentTrain(torch.utils.data.Dataset):
         self.save_result_dir, self.memory_size, self.transform = save_result_dir, memory_size, transform
         csv_path = os.path.join(save_result_dir, "memory_pool.csv")
         assert os.path.exists(csv_path), f"{csv_path} does not exist"
-        while True:                                  # the writer may be mid-rewrite (reference :43-51)
-            try:
-                pool = pd.read_csv(csv_path, index_col=0, low_memory=False)
-                break
-            except Exception:
-                print(f"catch some EXCEPTION when try to load {csv_path}")
-                time.sleep(10)
-        pool = pool.sample(min(pool.shape[0], self.memory_size))          # shuffle (np.random global state)
         self.seqs = []
         split_file = os.path.join(db_root_dir or "", "ImageSets", "2017", f"{split}.txt")
         if os.path.exists(split_file):
             with open(split_file) as f:
                 self.seqs = [ln.strip() for ln in f.readlines()]
-        if self.seq_list is not None:
-            assert len(self.seq_list) > 0
-            pool = pool[pool["sequence"].isin(set(self.seq_list))]
+        npz_path = os.path.join(save_result_dir, "memory_pool.npz")
+        soa = names = None
+        if os.path.exists(npz_path) and os.path.getmtime(npz_path) >= os.path.getmtime(csv_path):
+            # binary SoA sidecar written by ReplayMemory.sync_csv together with the CSV: same rows, no text parsing.
+            # The shuffle consumes np.random exactly like DataFrame.sample does (choice without replacement).
+            try:
+                with np.load(npz_path) as z:
+                    names = z["sequence"].astype(str)
+                    soa = {k: z[k] for k in ("action", "reward_step", "reward_done", "done", "old_state_iou", "new_state_iou",
+                                             "annotated_frames", "next_annotated_frames")}
+                pick = np.random.choice(len(names), size=min(len(names), self.memory_size), replace=False)
+                names, soa = names[pick], {k: v[pick] for k, v in soa.items()}
+                if self.seq_list is not None:
+                    assert len(self.seq_list) > 0
+                    keep = np.isin(names, list(self.seq_list))
+                    names, soa = names[keep], {k: v[keep] for k, v in soa.items()}
+                self.frame = None
+            except Exception:
+                soa = names = None
+        if soa is None:
+            while True:                              # the writer may be mid-rewrite (reference :43-51)
+                try:
+                    pool = pd.read_csv(csv_path, index_col=0, low_memory=False)
+                    break
+                except Exception:
+                    print(f"catch some EXCEPTION when try to load {csv_path}")
+                    time.sleep(10)
+            pool = pool.sample(min(pool.shape[0], self.memory_size))      # shuffle (np.random global state)
+            if self.seq_list is not None:
+                assert len(self.seq_list) > 0
+                pool = pool[pool["sequence"].isin(set(self.seq_list))]
+            names = pool["sequence"].to_numpy().astype(str)
+            self.frame = pool
+            soa = parse_rows(pool)
         if self.seqs:
-            unknown = set(pool["sequence"]) - set(self.seqs)
+            unknown = set(names) - set(self.seqs)
             assert not unknown, f"{sorted(unknown)[0]} not in {split} set."
-        self.frame = pool
-        soa = parse_rows(pool)
         self.soa = soa
+        npool = len(names)
         self.samples_list = [
             dict(action=soa["action"][i], old_state_iou=soa["old_state_iou"][i][None], new_state_iou=soa["new_state_iou"][i][None],
                  annotated_frames=soa["annotated_frames"][i][None], next_annotated_frames=soa["next_annotated_frames"][i][None],
                  reward_step=soa["reward_step"][i], reward_done=soa["reward_done"][i], done=soa["done"][i])
-            for i in range(len(pool))]
+            for i in range(npool)]
 
     def __len__(self):
         return len(self.samples_list)

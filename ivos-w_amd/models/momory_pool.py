@@ -5,7 +5,16 @@ Mirrors /root/reference/models/momory_pool.py:8-162 (``Transition`` field order,
 ``sample_th`` filter and the capacity shrink in ``load_from_csv``).  The module name keeps the reference's
 spelling ("momory") so imports drop in.  ``DeviceReplay`` is the MI355X-side addition: the same rows as a
 device-resident SoA that ``ivosw_replay_gather`` samples minibatches from.
+
+Persistence.  The reference re-serialises the whole DataFrame through pandas on every push
+(:126-153: O(N) per transition, ~100 MB of text at 50 k rows) and the dataset re-parses it every third sequence.
+Here the CSV image is kept as pre-formatted text rows: ``push_to_csv`` formats ONE row, and the file is rewritten by a
+single text join (no pandas) every ``csv_sync_every`` pushes (default 1 = the reference's behaviour: the file on disk is
+byte-identical to the reference's after every push; at capacity every row's index label shifts, so the format itself
+forbids a pure append).  Each sync also writes ``memory_pool.npz``, the same rows as a binary SoA that
+``datasets.agent_dataset`` loads instead of re-parsing the text.
 """
+import io
 import os
 import random
 from collections import namedtuple
@@ -32,7 +41,9 @@ class ReplayMemory:
         self.position = -1            # first push lands on slot 0
         self.basename_csv = "memory_pool.csv"
         self.COLUMNS = list(_CSV_COLUMNS)
-        self.memory_pd = pd.DataFrame(columns=self.COLUMNS)
+        self._rows, self._label0, self._memory_pd = [], 0, None      # CSV image: text rows + first index label
+        self._pending, self._needs_pandas, self._parsed = 0, False, {}
+        self.csv_sync_every = 1                    # 1 = rewrite memory_pool.csv on every push, like the reference
         self.seq_list = []
 
     def __len__(self):
@@ -100,14 +111,113 @@ class ReplayMemory:
                 "state_iou": t.state_iou, "next_state_iou": t.next_state_iou,
                 "annotated_frames": t.annotated_frames, "next_annotated_frames": t.next_annotated_frames}
 
+    # ---- CSV image as text rows -------------------------------------------------------------------------
+    @staticmethod
+    def _fmt(v):
+        """One cell exactly as ``DataFrame.to_csv`` writes it (QUOTE_MINIMAL), or None if it would need quoting."""
+        if isinstance(v, (bool, np.bool_)):
+            return "True" if v else "False"
+        if isinstance(v, (int, np.integer)):
+            return str(int(v))
+        if isinstance(v, (float, np.floating)):
+            return "" if v != v else repr(float(v))
+        t = str(v)
+        return None if any(ch in t for ch in ',"\r\n') else t
+
+    def _format_row(self, row):
+        cells = [self._fmt(row[c]) for c in self.COLUMNS]
+        return None if any(c is None for c in cells) else ",".join(cells)
+
+    def _rows_from_frame(self, frame):
+        """Text rows of a DataFrame exactly as pandas serialises them (labels stripped)."""
+        lines = frame.to_csv().split("\n")[1:]
+        return [ln.split(",", 1)[1] for ln in lines if ln]
+
+    @property
+    def memory_pd(self):
+        """The reference's DataFrame image of the pool, materialised on demand from the text rows."""
+        if self._memory_pd is None:
+            text = "," + ",".join(self.COLUMNS) + "\n" + "".join(f"{self._label0 + i},{r}\n" for i, r in enumerate(self._rows))
+            self._memory_pd = pd.read_csv(io.StringIO(text), index_col=0, float_precision="round_trip") if self._rows else pd.DataFrame(columns=self.COLUMNS)
+        return self._memory_pd
+
+    @memory_pd.setter
+    def memory_pd(self, frame):
+        self._memory_pd = frame
+        self._rows = self._rows_from_frame(frame) if len(frame) else []
+        self._label0 = int(frame.index.min()) if len(frame) else 0
+
+    def csv_text(self):
+        return "," + ",".join(self.COLUMNS) + "\n" + "".join(f"{self._label0 + i},{r}\n" for i, r in enumerate(self._rows))
+
+    def _write_csv(self, report_save_dir):
+        os.makedirs(report_save_dir, exist_ok=True)
+        path = os.path.join(report_save_dir, self.basename_csv)
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            f.write(self.csv_text())
+        os.replace(tmp, path)                      # readers never see a half-written file
+        self._pending = 0
+
+    def sync_csv(self, report_save_dir, sidecar=True):
+        """Write ``memory_pool.csv`` (byte-identical to the reference's file for the same push sequence) and, with
+        ``sidecar``, the binary SoA image ``memory_pool.npz`` of the same rows (parsed rows are cached per text row)."""
+        self._write_csv(report_save_dir)
+        if not sidecar:
+            return
+        try:
+            for r in self._rows:
+                if r not in self._parsed:
+                    self._parsed[r] = parse_text_rows([r])
+            if len(self._parsed) > 2 * len(self._rows) + 64:
+                live = set(self._rows)
+                self._parsed = {k: v for k, v in self._parsed.items() if k in live}
+            keys = ("action", "reward_step", "reward_done", "done", "old_state_iou", "new_state_iou", "annotated_frames",
+                    "next_annotated_frames")
+            soa = {k: np.concatenate([self._parsed[r][k] for r in self._rows]) for k in keys} if self._rows else parse_text_rows([])
+            np.savez(os.path.join(report_save_dir, "memory_pool.npz"), nrows=np.int64(len(self._rows)),
+                     sequence=np.array([r.split(",", 1)[0] for r in self._rows]), **soa)
+        except Exception:                          # ragged / non-numeric rows: the CSV stays the source of truth
+            pass
+
     def push_to_csv(self, report_save_dir):
-        """Append the most recent transition to the CSV image (dropping the oldest row when over capacity)
-        and rewrite ``memory_pool.csv`` — same file content as the reference (:126-153)."""
-        row = pd.DataFrame(data={k: [v] for k, v in self._row_at(self.position).items()}, columns=self.COLUMNS)
-        self.memory_pd = pd.concat([self.memory_pd, row], ignore_index=True)
-        if len(self.memory_pd) > self.capacity:
-            self.memory_pd = self.memory_pd.drop(self.memory_pd.index.min())
-        self.memory_pd.to_csv(os.path.join(report_save_dir, self.basename_csv))
+        """Append the most recent transition to the CSV image, dropping the oldest row when over capacity
+        (reference :126-153: concat with ignore_index, drop the smallest label, rewrite the file)."""
+        line = self._format_row(self._row_at(self.position))
+        if line is None or self._needs_pandas:
+            # a cell needs CSV quoting: fall back to the reference's own pandas path for this pool
+            self._needs_pandas = True
+            row = pd.DataFrame(data={k: [v] for k, v in self._row_at(self.position).items()}, columns=self.COLUMNS)
+            frame = pd.concat([self.memory_pd, row], ignore_index=True) if len(self.memory_pd) else row
+            if len(frame) > self.capacity:
+                frame = frame.drop(frame.index.min())
+            self._memory_pd = frame
+            os.makedirs(report_save_dir, exist_ok=True)
+            frame.to_csv(os.path.join(report_save_dir, self.basename_csv))
+            return
+        self._rows.append(line)
+        self._label0 = 0                           # concat(ignore_index=True) relabels from 0 ...
+        if len(self._rows) > self.capacity:
+            self._rows.pop(0)
+            self._label0 = 1                       # ... and dropping label 0 leaves 1..capacity
+        self._memory_pd = None
+        self._pending += 1
+        if self._pending >= self.csv_sync_every:
+            # every push (the reference's cadence): text only; deferred cadence: also refresh the binary sidecar
+            self.sync_csv(report_save_dir, sidecar=self.csv_sync_every > 1)
+
+
+def parse_text_rows(rows):
+    """Pre-formatted CSV rows (no label) -> the SoA dict of ``parse_rows`` without going through pandas."""
+    cols = list(zip(*(r.split(",") for r in rows))) if rows else [[] for _ in _CSV_COLUMNS]
+    by = dict(zip(_CSV_COLUMNS, cols))
+
+    def mat(col):
+        return np.array([[float(tok) for tok in s.split("/")] for s in by[col]], dtype=np.float64).reshape(len(rows), -1)
+    return dict(action=np.array(by["action"], dtype=np.int64), reward_step=np.array(by["reward_step"], dtype=np.int64),
+                reward_done=np.array(by["reward_done"], dtype=np.float64), done=np.array([d == "True" for d in by["done"]], dtype=bool),
+                old_state_iou=mat("state_iou"), new_state_iou=mat("next_state_iou"),
+                annotated_frames=mat("annotated_frames"), next_annotated_frames=mat("next_annotated_frames"))
 
 
 def parse_rows(frame, T=None):

@@ -82,3 +82,88 @@ def test_random_sample_surface():
         mem.push({}, i, {}, 1, 0.0, False, "0.1", "0.2", "0.0", "1.0")
     s = mem.random_sample(2)
     assert isinstance(s, Transition) and len(s.action) == 2
+
+
+# ---------------------------------------------------------------- §8(f) rank 2: persistence without pandas on the hot path
+def _reference_push_to_csv(frame, row, capacity, columns):
+    """The reference's push_to_csv (models/momory_pool.py:126-153) restated with pandas, as the checker."""
+    frame = pd.concat([frame, pd.DataFrame(data={k: [v] for k, v in row.items()}, columns=columns)], ignore_index=True) \
+        if len(frame) else pd.DataFrame(data={k: [v] for k, v in row.items()}, columns=columns)
+    if len(frame) > capacity:
+        frame = frame.drop(frame.index.min())
+    return frame
+
+
+def _random_rows(n, T, seed):
+    rs = np.random.RandomState(seed)
+    seqs = ["bear", "camel", "drift-chicane", "india", "kite_surf"]
+    j = lambda a: "/".join(str(round(float(x), 4)) for x in a)
+    rows = []
+    for i in range(n):
+        k = int(rs.randint(1, 5))
+        rows.append(dict(sequence=seqs[int(rs.randint(len(seqs)))], scribble_iter=int(rs.randint(1, 4)), n_interaction=k,
+                         n_interaction_next=k + 1, action=int(rs.randint(T)), reward_step=int(rs.choice([1, -1])),
+                         reward_done=float(rs.randn()) if rs.rand() < 0.9 else float(int(rs.randint(-2, 3))),
+                         done=bool(rs.rand() < 0.3), state_iou=j(rs.rand(T)), next_state_iou=j(rs.rand(T)),
+                         annotated_frames=j(rs.randint(0, 2, T).astype(float)), next_annotated_frames=j(rs.randint(0, 3, T).astype(float))))
+    return rows
+
+
+def _push(mem, r):
+    st = dict(sequence=r["sequence"], scribble_iter=r["scribble_iter"], n_interaction=r["n_interaction"])
+    nst = dict(st, n_interaction=r["n_interaction_next"])
+    mem.push(st, r["action"], nst, r["reward_step"], r["reward_done"], r["done"], r["state_iou"], r["next_state_iou"],
+             r["annotated_frames"], r["next_annotated_frames"])
+
+
+@pytest.mark.parametrize("capacity,n", [(6, 17), (50, 20)])
+def test_text_row_writer_is_byte_identical_to_the_pandas_path(tmp_path, capacity, n):
+    mem = ReplayMemory(capacity)
+    frame = pd.DataFrame(columns=mem.COLUMNS)
+    for r in _random_rows(n, T=5, seed=capacity):
+        _push(mem, r)
+        mem.push_to_csv(str(tmp_path))
+        frame = _reference_push_to_csv(frame, r, capacity, mem.COLUMNS)
+        assert open(tmp_path / "memory_pool.csv").read() == frame.to_csv()
+    assert mem.memory_pd.to_csv() == frame.to_csv()                                  # the DataFrame view of the same rows
+
+
+def test_deferred_sync_and_sidecar(tmp_path):
+    rows = _random_rows(23, T=4, seed=3)
+    mem = ReplayMemory(10)
+    mem.csv_sync_every = 8
+    frame = pd.DataFrame(columns=mem.COLUMNS)
+    for i, r in enumerate(rows):
+        _push(mem, r)
+        mem.push_to_csv(str(tmp_path))
+        frame = _reference_push_to_csv(frame, r, 10, mem.COLUMNS)
+        if (i + 1) % 8 == 0:
+            assert open(tmp_path / "memory_pool.csv").read() == frame.to_csv()       # written every 8th push ...
+    assert open(tmp_path / "memory_pool.csv").read() != frame.to_csv()               # ... and stale in between
+    mem.sync_csv(str(tmp_path))
+    assert open(tmp_path / "memory_pool.csv").read() == frame.to_csv()
+    # the binary sidecar holds the same rows; the dataset built from it equals the one parsed from the CSV text
+    np.random.seed(11)
+    a = DAVIS2017AgentTrain(split="train", db_root_dir=str(tmp_path / "nope"), save_result_dir=str(tmp_path), memory_size=100,
+                            seq_list=["bear", "india", "kite_surf"])
+    assert a.frame is None                                                           # came from memory_pool.npz
+    os.remove(tmp_path / "memory_pool.npz")
+    np.random.seed(11)
+    b = DAVIS2017AgentTrain(split="train", db_root_dir=str(tmp_path / "nope"), save_result_dir=str(tmp_path), memory_size=100,
+                            seq_list=["bear", "india", "kite_surf"])
+    assert b.frame is not None and len(a) == len(b) > 0
+    for x, y in zip(a.samples_list, b.samples_list):
+        assert set(x) == set(y)
+        for k in x:
+            assert np.asarray(x[k]).dtype == np.asarray(y[k]).dtype and np.array_equal(x[k], y[k]), k
+
+
+def test_cells_that_need_quoting_fall_back_to_pandas(tmp_path):
+    mem = ReplayMemory(3)
+    frame = pd.DataFrame(columns=mem.COLUMNS)
+    for r in _random_rows(5, T=3, seed=9):
+        r = dict(r, sequence=r["sequence"] + ",take 2")
+        _push(mem, r)
+        mem.push_to_csv(str(tmp_path))
+        frame = _reference_push_to_csv(frame, r, 3, mem.COLUMNS)
+        assert open(tmp_path / "memory_pool.csv").read() == frame.to_csv()
