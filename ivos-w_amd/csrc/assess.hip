@@ -22,6 +22,7 @@ struct ConvPlan {
 
 struct BlockPlan {
     int c1, c2, c3, ds;  // indices into convs (ds = -1 if none)
+    size_t cat_w_off, cat_b_off;  // first blocks: conv3 | downsample concatenated along K, bias sum (conv3 absorbs the downsample conv)
 };
 
 struct Plan {
@@ -66,6 +67,10 @@ static Plan make_plan(int dtype) {
             bp.c2 = add(planes[s], planes[s], 3, st);
             bp.c3 = add(planes[s], planes[s] * 4, 1, 1);
             bp.ds = (b == 0) ? add(inpl, planes[s] * 4, 1, st) : -1;
+            if (b == 0) {
+                bp.cat_w_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
+                bp.cat_b_off = take((size_t)planes[s] * 4 * sizeof(float));
+            }
             P.blocks.push_back(bp);
             inpl = planes[s] * 4;
         }
@@ -152,6 +157,13 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
         launch_pack_conv(T(c.t_w), T(c.t_bn), T(c.t_bn + 1), T(c.t_bn + 2), T(c.t_bn + 3), c.Cout, c.Cin, c.K, c.K, dtype,
                          base + c.w_off, reinterpret_cast<float*>(base + c.b_off), st);
     }
+    for (const BlockPlan& bp : P.blocks)
+        if (bp.ds >= 0) {
+            const ConvPlan &c3 = P.convs[bp.c3], &cd = P.convs[bp.ds];
+            launch_concat_k(base + c3.w_off, reinterpret_cast<const float*>(base + c3.b_off), c3.Cin, base + cd.w_off,
+                            reinterpret_cast<const float*>(base + cd.b_off), cd.Cin, c3.Cout, dtype, base + bp.cat_w_off,
+                            reinterpret_cast<float*>(base + bp.cat_b_off), st);
+        }
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
@@ -239,6 +251,21 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
             mk(c1, x, hw, hw, nullptr, bf.m1, 1);
             mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
             const void* idt = x;
+            if (bp.ds >= 0 && tune_get("FUSE_DS", 1)) {
+                // first block of a stage: relu(conv3(t2) + downsample(x)) as ONE GEMM over K = C + Cin (the block input,
+                // sampled at the downsample stride, is the second A source): the 4C-channel downsample output never
+                // goes to HBM and back
+                const ConvPlan& cd = P.convs[bp.ds];
+                ConvArgs q{};
+                q.zeros = base + P.zero_off; q.x = bf.m2; q.w = base + bp.cat_w_off; q.bias = reinterpret_cast<const float*>(base + bp.cat_b_off);
+                q.res = nullptr; q.y = y; q.B = nb; q.H = ho; q.W = ho; q.Cin = c3.Cin; q.Ho = ho; q.Wo = ho; q.Cout = c3.Cout;
+                q.KH = 1; q.KW = 1; q.stride = 1; q.pad = 0; q.relu = 1;
+                q.x2 = x; q.Cin2 = cd.Cin; q.H2 = hw; q.W2 = hw; q.stride2 = cd.stride;
+                launch_conv(q, dtype, false, st);
+                x = y;
+                hw = ho;
+                continue;
+            }
             if (bp.ds >= 0) {
                 mk(P.convs[bp.ds], x, hw, ho, nullptr, bf.ds, 0);
                 idt = bf.ds;

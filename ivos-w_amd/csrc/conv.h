@@ -12,6 +12,10 @@ struct ConvArgs {
     void* y;            // NHWC [B,Ho,Wo,Cout]
     const void* zeros;  // >= 16 B of device zeros: source of the zero-padding taps for the LDS-DMA loader
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu;
+    // optional K-extension (1x1 only): a SECOND input tensor x2 [B,H2,W2,Cin2] sampled at (oy*stride2, ox*stride2) supplies
+    // K-tiles Cin/64 .. (Cin+Cin2)/64 - 1; the weights are [Cout][Cin + Cin2].  Folds a block's downsample conv into conv3.
+    const void* x2;
+    int Cin2, H2, W2, stride2;
     int nmajor;         // tile order of the wave-specialised kernel: 0 m-major, 1 n-major
     int nt;             // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (generic epilogue), bit 2: also in the patch / fused kernels (tunable NT, default 3)
     int debug;          // ablation bits (IVOSW_DEBUG_CONV, tuning only): 1 skip epilogue stores, 2 skip MFMA, 4 skip DMA after the first tile
@@ -43,6 +47,9 @@ void launch_bneck(const BneckArgs& a, hipStream_t st);
 int tune_get(const char* key, int dflt);
 void launch_pack_conv(const float* w, const float* g, const float* b, const float* rm, const float* rv, int Cout, int Cin,
                       int KH, int KW, int dtype, void* ow, float* ob, hipStream_t st);
+// [Cout][K1] | [Cout][K2] -> [Cout][K1+K2] (same dtype), bias = b1 + b2
+void launch_concat_k(const void* w1, const float* b1, int K1, const void* w2, const float* b2, int K2, int Cout, int dtype,
+                     void* ow, float* ob, hipStream_t st);
 void launch_pack_stem(const float* w3, const float* w1, const float* g, const float* b, const float* rm, const float* rv,
                       int dtype, void* ow, float* ob, hipStream_t st);
 // bf16: stem 7x7/2 + BN + ReLU + 3x3/2 max-pool fused (stem.hip): roi [B,256,256,4] -> out [B,64,64,64]

@@ -283,20 +283,23 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
     const int M = p.B * p.Ho * p.Wo;
 
     const T* X = static_cast<const T*>(p.x);
+    const T* X2 = static_cast<const T*>(p.x2);
     const T* Wt = static_cast<const T*>(p.w);
-    const int K = p.KH * p.KW * p.Cin;
+    const int K = p.KH * p.KW * p.Cin + (X2 ? p.Cin2 : 0);
     const int nk = K / KE;
+    const int nk1 = p.KH * p.KW * p.Cin / KE;        // K-tiles of the first source
     const int ctiles = p.Cin / KE;
 
     // ---- this lane's DMA duty: row (l>>3) of each of the wave's 8-row groups, chunk position (l&7)
     const int rsub = lane >> 3, cpos = lane & 7;
-    long abase[AG];
+    long abase[AG], abase2[AG];
     int aiy[AG], aix[AG], achunk[AG];
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
         const int row = (wave * AG + i) * 8 + rsub;
         achunk[i] = (cpos ^ ((row >> 1) & 7)) * CE;
         const int m = m0 + row;
+        abase2[i] = -1;
         if (m < M) {
             const int b = m / (p.Ho * p.Wo);
             const int rem = m - b * (p.Ho * p.Wo);
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
             aiy[i] = oy * p.stride - p.pad;
             aix[i] = ox * p.stride - p.pad;
             abase[i] = (long)b * p.H * p.W * p.Cin;
+            if (X2) abase2[i] = (((long)b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.Cin2 + achunk[i];
         } else {
             aiy[i] = -100000; aix[i] = -100000; abase[i] = 0;
         }
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
             const int iy = aiy[i] + ky, ix = aix[i] + kx;
             const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const T* src = ok ? X + abase[i] + ((long)iy * p.W + ix) * p.Cin + c0 + achunk[i] : zeros;
+            if (kt >= nk1) src = abase2[i] >= 0 ? X2 + abase2[i] + (long)(kt - nk1) * KE : zeros;   // K-extension: second source
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (wave * AG + i) * 1024), 16, 0, 0);
         }
 #pragma unroll
@@ -459,24 +464,27 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
     const int tile_n = p.nmajor ? L / nbm : L % nbn, tile_m = p.nmajor ? L % nbm : L / nbn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int M = p.B * p.Ho * p.Wo;
-    const int K = p.KH * p.KW * p.Cin;
+    const int K = p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
     const int nk = K / KE;
 
     if (wave >= NW) {
         // ================= loader wave =================
         const int lw = wave - NW;
         const T* X = static_cast<const T*>(p.x);
+        const T* X2 = static_cast<const T*>(p.x2);
         const T* Wt = static_cast<const T*>(p.w);
         const T* zeros = static_cast<const T*>(p.zeros);
         const int ctiles = p.Cin / KE;
+        const int nk1 = p.KH * p.KW * p.Cin / KE;
         const int rsub = lane >> 3, cpos = lane & 7;
-        long abase[AG];
+        long abase[AG], abase2[AG];
         int aiy[AG], aix[AG], achunk[AG];
 #pragma unroll
         for (int i = 0; i < AG; ++i) {
             const int row = (lw * AG + i) * 8 + rsub;
             achunk[i] = (cpos ^ ((row >> 1) & 7)) * CE;
             const int m = m0 + row;
+            abase2[i] = -1;
             if (m < M) {
                 const int b = m / (p.Ho * p.Wo);
                 const int rem = m - b * (p.Ho * p.Wo);
@@ -484,6 +492,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
                 aiy[i] = oy * p.stride - p.pad;
                 aix[i] = ox * p.stride - p.pad;
                 abase[i] = (long)b * p.H * p.W * p.Cin;
+                if (X2) abase2[i] = (((long)b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.Cin2 + achunk[i];
             } else {
                 aiy[i] = -100000; aix[i] = -100000; abase[i] = 0;
             }
@@ -503,6 +512,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
                 const int iy = aiy[i] + ky, ix = aix[i] + kx;
                 const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 const T* src = ok ? X + abase[i] + ((long)iy * p.W + ix) * p.Cin + c0 + achunk[i] : zeros;
+                if (kt >= nk1) src = abase2[i] >= 0 ? X2 + abase2[i] + (long)(kt - nk1) * KE : zeros;   // K-extension: second source
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (lw * AG + i) * 1024), 16, 0, 0);
             }
 #pragma unroll
@@ -831,7 +841,7 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
         // Tile / ring selection.  8 waves (2 per SIMD) so one wave's LDS-DMA issue overlaps the other's MFMAs;
         // 256-row tiles halve the DMA instructions per MFMA.  Short K loops (1x1 convs on 64/128 channels) use a
         // 2-deep ring.
-        const int nk = a.KH * a.KW * a.Cin / (128 / (int)sizeof(T));
+        const int nk = (a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0)) / (128 / (int)sizeof(T));
         if (a.Cout % 128 == 0) {
             const int grid = ((M + 255) / 256) * (a.Cout / 128);
             static const int tune_nk = getenv("IVOSW_TUNE_NK") ? atoi(getenv("IVOSW_TUNE_NK")) : 8;
@@ -956,6 +966,27 @@ void launch_pack_conv(const float* w, const float* g, const float* b, const floa
         hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, grid, dim3(256), 0, st, w, g, b, rm, rv, 1e-5f, Cout, Cin, KH, KW, static_cast<bf16_t*>(ow), ob);
     else
         hipLaunchKernelGGL(pack_conv_kernel<float>, grid, dim3(256), 0, st, w, g, b, rm, rv, 1e-5f, Cout, Cin, KH, KW, static_cast<float*>(ow), ob);
+}
+
+template <typename T>
+__global__ void concat_k_kernel(const T* __restrict__ w1, const float* __restrict__ b1, int K1, const T* __restrict__ w2,
+                                const float* __restrict__ b2, int K2, int Cout, T* __restrict__ ow, float* __restrict__ ob) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = K1 + K2;
+    if (i >= (long)Cout * K) return;
+    const int co = (int)(i / K), k = (int)(i - (long)co * K);
+    ow[i] = k < K1 ? w1[(long)co * K1 + k] : w2[(long)co * K2 + (k - K1)];
+    if (k == 0) ob[co] = b1[co] + b2[co];
+}
+
+void launch_concat_k(const void* w1, const float* b1, int K1, const void* w2, const float* b2, int K2, int Cout, int dtype,
+                     void* ow, float* ob, hipStream_t st) {
+    const long n = (long)Cout * (K1 + K2);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == IVOSW_BF16)
+        hipLaunchKernelGGL(concat_k_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(w1), b1, K1, static_cast<const bf16_t*>(w2), b2, K2, Cout, static_cast<bf16_t*>(ow), ob);
+    else
+        hipLaunchKernelGGL(concat_k_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(w1), b1, K1, static_cast<const float*>(w2), b2, K2, Cout, static_cast<float*>(ow), ob);
 }
 
 void launch_pack_stem(const float* w3, const float* w1, const float* g, const float* b, const float* rm, const float* rv,
@@ -1107,7 +1138,7 @@ extern "C" int ivosw_profile_report(char* buf, size_t cap) {
         const ConvArgs& a = r.a;
         const double M = (double)a.B * a.Ho * a.Wo;
         const double cm = a.Cout / 4.0;
-        const double flops = a.KH ? 2.0 * M * a.Cout * a.KH * a.KW * a.Cin : 2.0 * M * (a.Cin * cm + 9.0 * cm * cm + cm * a.Cout);
+        const double flops = a.KH ? 2.0 * M * a.Cout * (a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0)) : 2.0 * M * (a.Cin * cm + 9.0 * cm * cm + cm * a.Cout);
         const double bytes = a.KH ? ((double)a.B * a.H * a.W * a.Cin + M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * a.KH * a.KW * a.Cin) * r.es
                                   : (M * (a.Cin + a.Cout) + a.Cin * cm + 13.0 * cm * cm) * r.es;
         const double t = r.ms / r.n * 1e-3;
