@@ -134,16 +134,28 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
     const size_t plane = (size_t)H * W;
-    const size_t o_nw = (size_t)y0 * W + x0;
-    float out[4];
+    // All 16 taps are loaded unconditionally from clamped addresses and out-of-range taps get weight 0 (zero padding:
+    // they contribute +0, which leaves the fp32 sum bit-identical): predicated loads made hipcc branch around every
+    // load and wait for it, 16 dependent round trips per pixel.
+    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+    const size_t o00 = (size_t)yc0 * W + xc0, o01 = (size_t)yc0 * W + xc1, o10 = (size_t)yc1 * W + xc0, o11 = (size_t)yc1 * W + xc1;
+    const float k_nw = (vy0 && vx0) ? w_nw : 0.f, k_ne = (vy0 && vx1) ? w_ne : 0.f;
+    const float k_sw = (vy1 && vx0) ? w_sw : 0.f, k_se = (vy1 && vx1) ? w_se : 0.f;
+    float v[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float* src = (c < 3) ? tf + ((size_t)b * 3 + c) * plane : tp + (size_t)b * plane;
-        float acc = 0.f;  // zero padding: out-of-range taps contribute nothing
-        if (vy0 && vx0) acc = __fadd_rn(acc, __fmul_rn(src[o_nw], w_nw));
-        if (vy0 && vx1) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + 1], w_ne));
-        if (vy1 && vx0) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + W], w_sw));
-        if (vy1 && vx1) acc = __fadd_rn(acc, __fmul_rn(src[o_nw + W + 1], w_se));
+        v[c][0] = src[o00]; v[c][1] = src[o01]; v[c][2] = src[o10]; v[c][3] = src[o11];
+    }
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float acc = 0.f;
+        acc = __fadd_rn(acc, __fmul_rn(v[c][0], k_nw));
+        acc = __fadd_rn(acc, __fmul_rn(v[c][1], k_ne));
+        acc = __fadd_rn(acc, __fmul_rn(v[c][2], k_sw));
+        acc = __fadd_rn(acc, __fmul_rn(v[c][3], k_se));
         if (c < 3) {  // (f - mean) / std after the zero pad (assessment.py:47)
             const float mu = nrm.dev ? nrm.dev[c] : nrm.mean[c], sd = nrm.dev ? nrm.dev[3 + c] : nrm.std[c];
             acc = __fsub_rn(acc, mu) / sd;
@@ -154,9 +166,7 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict
     if constexpr (sizeof(T) == 4) {
         *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
     } else {
-        ushort4 v;
-        v.x = f32_to_bf16(out[0]); v.y = f32_to_bf16(out[1]); v.z = f32_to_bf16(out[2]); v.w = f32_to_bf16(out[3]);
-        *reinterpret_cast<ushort4*>(dst) = v;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_bf16(out[0], out[1]), pack2_bf16(out[2], out[3]));
     }
 }
 
