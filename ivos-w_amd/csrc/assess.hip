@@ -23,6 +23,7 @@ struct ConvPlan {
 struct BlockPlan {
     int c1, c2, c3, ds;  // indices into convs (ds = -1 if none)
     size_t cat_w_off, cat_b_off;  // first blocks: conv3 | downsample concatenated along K, bias sum (conv3 absorbs the downsample conv)
+    size_t f1_off, f2_off, f3_off;  // bf16, res4 identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
 };
 
 struct Plan {
@@ -70,6 +71,10 @@ static Plan make_plan(int dtype) {
             if (b == 0) {
                 bp.cat_w_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
                 bp.cat_b_off = take((size_t)planes[s] * 4 * sizeof(float));
+            } else if (dtype == IVOSW_BF16 && s == 2) {
+                bp.f1_off = take((size_t)planes[s] * inpl * es);
+                bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
+                bp.f3_off = take((size_t)planes[s] * 4 * planes[s] * es);
             }
             P.blocks.push_back(bp);
             inpl = planes[s] * 4;
@@ -158,6 +163,13 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
                          base + c.w_off, reinterpret_cast<float*>(base + c.b_off), st);
     }
     for (const BlockPlan& bp : P.blocks)
+        if (bp.f1_off) {
+            const ConvPlan &c1 = P.convs[bp.c1], &c2 = P.convs[bp.c2], &c3 = P.convs[bp.c3];
+            launch_fragpack(base + c1.w_off, c1.Cout, c1.Cin, base + bp.f1_off, st);
+            launch_fragpack(base + c2.w_off, c2.Cout, 9 * c2.Cin, base + bp.f2_off, st);
+            launch_fragpack(base + c3.w_off, c3.Cout, c3.Cin, base + bp.f3_off, st);
+        }
+    for (const BlockPlan& bp : P.blocks)
         if (bp.ds >= 0) {
             const ConvPlan &c3 = P.convs[bp.c3], &cd = P.convs[bp.ds];
             launch_concat_k(base + c3.w_off, reinterpret_cast<const float*>(base + c3.b_off), c3.Cin, base + cd.w_off,
@@ -244,6 +256,19 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
                 if (bneck_fusable(q)) {
                     launch_bneck(q, st);
+                    x = y;
+                    continue;
+                }
+            }
+            if (dtype == IVOSW_BF16 && bp.f1_off && tune_get("FUSE_WIDE", 1)) {
+                BneckWideArgs q{};
+                q.x = x; q.y = y;
+                q.fa = base + bp.f1_off; q.ba = reinterpret_cast<const float*>(base + c1.b_off);
+                q.fb = base + bp.f2_off; q.bb = reinterpret_cast<const float*>(base + c2.b_off);
+                q.fc = base + bp.f3_off; q.bc = reinterpret_cast<const float*>(base + c3.b_off);
+                q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
+                if (bneck_wide_fusable(q)) {
+                    launch_bneck_wide(q, st);
                     x = y;
                     continue;
                 }

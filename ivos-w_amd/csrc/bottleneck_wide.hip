@@ -1,0 +1,340 @@
+// Whole-bottleneck fusion for the wide stages (bf16): res4's identity blocks (C = 256, 16x16 frames, 1024 -> 256 ->
+// 256 (3x3) -> 1024 + residual).
+//
+// Reference arithmetic: torchvision ResNet-50 v1.5 Bottleneck as Encoder.forward runs it (models/assessment.py:60),
+//     out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x),  BN folded into weights + bias.
+//
+// Layer by layer these blocks sit at 2.3 TB/s of HBM and 25 % MFMA busy: each of the three launches is bound by the
+// LDS-DMA fill path (weights AND activations stream through one in-order queue per wave and retire at the pace of its
+// DRAM misses) with its phases serialised by a barrier per K-tile.  The dataflow here is different from bottleneck.hip:
+//
+//   * one workgroup = one FRAME (16 x 16 = 256 pixels): no halo, no recompute; the 3x3's zero padding is a lane
+//     predicate on the shifted fragment read;
+//   * the intermediates t1 and t2 (256 px x 256 ch bf16 = 128 KB) live in LDS as four 64-channel slices of the usual
+//     swizzled [row][128 B] image, t2 overwriting t1;
+//   * wave w owns output-channel tile w (32 channels) x all 8 pixel tiles (128 accumulator registers) in every
+//     contraction, so a weight fragment is needed by exactly ONE wave: weights never touch LDS.  They are stored
+//     pre-arranged in fragment order (launch_fragpack: [channel tile][k step][lane][16 B], 1 KB per MFMA operand) and
+//     each wave streams its own slice with plain coalesced 16-B loads, two K-tiles ahead of use, with no barrier.
+//     Only x (phase A) goes through an LDS-DMA ring; phases B and C run barrier-free.
+//   * "transposed" MFMAs (A = weights, B = pixels): a lane holds 4 consecutive channels of one pixel, so t1 / t2 are
+//     written with ds_write_b64 and the final tile goes through a 4-KB per-wave staging tile to 64-B row segments.
+//
+// LDS: [0, 131072) x ring (4 x 32 KB) -> t1 -> t2 ; [131072, 163840) per-wave store staging (8 x 4 KB).
+#include "conv.h"
+#include "mfma_tile.h"
+
+namespace ivosw {
+
+namespace {
+constexpr int WC = 256, WCIN = 1024, WHW = 16, WNPX = WHW * WHW;   // res4 identity block
+constexpr int SLICE = WNPX * ROWB;                                   // 32 KB: one 64-channel slice of a 256-pixel image
+constexpr int IMG_BYTES = 4 * SLICE;                                 // 128 KB
+constexpr int STG_OFF = IMG_BYTES;                                   // 8 x 4 KB
+constexpr int WIDE_LDS = IMG_BYTES + 8 * 4096;
+static_assert(WIDE_LDS == 163840, "LDS map");
+
+// one MFMA weight operand of the fragment-ordered copy: channel tile ct, k-step ks of KS per tile
+__device__ __forceinline__ const uint4* wfrag(const void* base, int ct, int KS, int ks, int lane) {
+    return reinterpret_cast<const uint4*>(static_cast<const char*>(base) + ((size_t)(ct * KS + ks) * 64 + lane) * 16);
+}
+__device__ __forceinline__ u32x4 as_u32x4(uint4 v) {
+    u32x4 r = {v.x, v.y, v.z, v.w};
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];   // the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int b = blockIdx.x;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * WNPX * WCIN;
+    bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * WNPX * WCIN;
+
+    f32x16 acc[8];                                   // [pixel tile] for this wave's channel tile
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+    // pixel-operand fragment reads in two rolling halves (pixel tiles 0-3 / 4-7): the half just consumed is re-read
+    // for the next k-step while the other half's four MFMAs run
+    u32x4 pf[8];
+
+    // ================================================================ phase A: t1 = relu(Wa x + ba), K = 1024
+    {
+        constexpr int NK = WCIN / 64;                // 16 K-tiles of x through a 4-slot ring; wave-private Wa fragments
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const bf16_t* xsrc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + rsub;
+            xsrc[i] = X + (size_t)row * WCIN + (cpos ^ ((row >> 1) & 7)) * 8;
+        }
+        auto issue_x = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma16(xsrc[i] + kt * 64, lds + (kt & 3) * SLICE + (wave * 4 + i) * 1024);
+        };
+        u32x4 wq[2][4];                              // weight fragments of two K-tiles (inline-asm loads: counted by hand
+        auto load_w = [&](int kt, int set) {         // next to the LDS-DMA queue, hipcc would drain it at every use)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, wave, WCIN / 16, kt * 4 + ks, lane)) : "memory");
+        };
+        zero_acc();
+        // queue per wave: W0 X0 X1 | iter kt: W(kt+1) X(kt+2) -> at the top of iter kt only X(kt+1) is younger than W(kt)
+        load_w(0, 0);
+        issue_x(0);
+        issue_x(1);
+        for (int kt2 = 0; kt2 < NK; kt2 += 2)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {          // par == kt & 1: register-set index is a compile-time constant
+            const int kt = kt2 + par;
+            if (kt + 1 < NK) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();            // x tile kt landed for every wave; tile kt-1 is done: slot (kt+2)&3 is free
+            asm volatile("" ::: "memory");
+            if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
+            if (kt + 2 < NK) issue_x(kt + 2);
+            const unsigned xb = lds_base + (kt & 3) * SLICE;
+            auto rd = [&](int ks, int half) {
+                const int ch = 2 * ks + lhalf;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(xb + swz((half * 4 + i) * 32 + lrow, ch));
+            };
+            rd(0, 0);
+            rd(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 w = wq[par][ks];
+                lgkm_wait<4>();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                if (ks < 3) rd(ks + 1, 0);
+                if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
+#pragma unroll
+                for (int i = 4; i < 8; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                if (ks < 3) rd(ks + 1, 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // every wave is done with the ring: its space becomes t1
+        asm volatile("" ::: "memory");
+    }
+    // accumulators -> relu(acc + bias) -> bf16 -> image slice (wave >> 1), chunks 4*(wave & 1) + g
+    auto store_img = [&](const float* bias) {
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bias + wave * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int px = i * 32 + lrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
+                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
+                lds_write_b64(lds_base + (wave >> 1) * SLICE + px * ROWB + ((((wave & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    store_img(p.ba);
+
+    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x 4 slices
+    {
+        zero_acc();
+        // this lane's pixel in each tile: y = 2*tile + (lrow >> 4), x = lrow & 15
+        const int px_x = lrow & 15, px_yo = lrow >> 4;
+        uint4 wn[4], wc[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, wave, 9 * WC / 16, ks, lane);
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
+            const bool vx = (unsigned)(px_x + kx) < (unsigned)WHW;
+            // shifted source row of this lane in every pixel tile (invalid lanes read a clamped row and get zeros)
+            unsigned roff[8];                        // byte offset of the row; its swizzle key is (row >> 1) & 7 = (roff >> 8) & 7
+            unsigned vmask = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int y = 2 * i + px_yo + ky;
+                const bool ok = vx && (unsigned)y < (unsigned)WHW;
+                const int q = ok ? y * WHW + px_x + kx : 0;
+                roff[i] = q * ROWB;
+                vmask |= ok ? (1u << i) : 0u;
+            }
+#pragma unroll 1
+            for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wc[ks] = wn[ks];
+                const int nstep = (tap * 4 + sl + 1) * 4;       // next (tap, slice)'s fragments: in flight under this one's MFMAs
+                if (nstep < 9 * WC / 16) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, wave, 9 * WC / 16, nstep + ks, lane);
+                }
+                const unsigned tb = lds_base + sl * SLICE;
+                auto rd = [&](int ks, int half) {
+                    const int ch = 2 * ks + lhalf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int t = half * 4 + i;
+                        pf[t] = lds_read_b128(tb + roff[t] + ((ch ^ ((roff[t] >> 8) & 7)) << 4));
+                    }
+                };
+                auto mm = [&](const u32x4 w, int half) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int t = half * 4 + i;
+                        u32x4 v = pf[t];
+                        if (!((vmask >> t) & 1u)) v = u32x4{0, 0, 0, 0};
+                        acc[t] = mfma_bf16(w, v, acc[t]);
+                    }
+                };
+                rd(0, 0);
+                rd(0, 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 w = as_u32x4(wc[ks]);
+                    lgkm_wait<4>();
+                    mm(w, 0);
+                    if (ks < 3) rd(ks + 1, 0);
+                    if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
+                    mm(w, 1);
+                    if (ks < 3) rd(ks + 1, 1);
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
+        asm volatile("" ::: "memory");
+    }
+    store_img(p.bb);
+
+    // ================================================================ phase C: y = relu(Wc t2 + bc + x), 4 chunks of 256 channels
+    {
+        float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
+        const int u = lane & 3, prr = lane >> 2;     // store pass: 8-channel group u of the wave's 32 channels, pixel sub-row prr
+        uint4 wn[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, WC / 16, ks, lane);
+#pragma unroll 1
+        for (int chunk = 0; chunk < 4; ++chunk) {
+            const int ct = chunk * 8 + wave;         // output channel tile of this wave in this chunk
+            {
+                float4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bc + ct * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+                    }
+            }
+#pragma unroll 1
+            for (int sl = 0; sl < 4; ++sl) {         // K = 256: slice sl of t2, 4 k-steps each
+                uint4 wc[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wc[ks] = wn[ks];
+                const int nxt = chunk * 4 + sl + 1;  // next (chunk, slice): channel tile (nxt >> 2) * 8 + wave, k-steps (nxt & 3) * 4 ..
+                if (nxt < 16) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, (nxt >> 2) * 8 + wave, WC / 16, (nxt & 3) * 4 + ks, lane);
+                }
+                const unsigned tb = lds_base + sl * SLICE;
+                auto rd = [&](int ks, int half) {
+                    const int ch = 2 * ks + lhalf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(tb + swz((half * 4 + i) * 32 + lrow, ch));
+                };
+                rd(0, 0);
+                rd(0, 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 w = as_u32x4(wc[ks]);
+                    lgkm_wait<4>();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 0);
+                    if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
+#pragma unroll
+                    for (int i = 4; i < 8; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 1);
+                }
+            }
+            // store pass, one pixel tile at a time through the wave's 4-KB staging tile [32 px][32 ch] fp32 (16-B slots
+            // XOR-swizzled by the pixel row): + residual -> ReLU -> bf16 -> 64-B row segments
+            const size_t cofs = (size_t)ct * 32 + 8 * u;
+            uint4 rr[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + (size_t)(it * 16 + prr) * WCIN + cofs);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int slot = (2 * g + lhalf) ^ (lrow & 7);
+                    *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                }
+                uint4 rn[2];
+                if (i < 7) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) rn[it] = *reinterpret_cast<const uint4*>(X + (size_t)((i + 1) * 32 + it * 16 + prr) * WCIN + cofs);
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int pr = it * 16 + prr;
+                    const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u) ^ (pr & 7)) << 2));
+                    const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u + 1) ^ (pr & 7)) << 2));
+                    const unsigned w4[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                    *reinterpret_cast<uint4*>(Y + (size_t)(i * 32 + pr) * WCIN + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+                if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
+            }
+        }
+    }
+}
+
+// [Cout][K] K-major packed bf16 weights -> MFMA-operand order [Cout/32][K/16][64 lanes][8]: lane l of fragment (ct, ks)
+// holds row ct*32 + (l & 31), k = ks*16 + 8*(l >> 5) .. +8
+__global__ void fragpack_kernel(const bf16_t* __restrict__ w, int Cout, int K, bf16_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-B chunk per thread
+    const long nchunk = (long)Cout * K / 8;
+    if (i >= nchunk) return;
+    const int l = (int)(i & 63);
+    const long f = i >> 6;
+    const int KS = K / 16;
+    const int ct = (int)(f / KS), ks = (int)(f - (long)ct * KS);
+    const uint4 v = *reinterpret_cast<const uint4*>(w + (size_t)(ct * 32 + (l & 31)) * K + ks * 16 + 8 * (l >> 5));
+    *reinterpret_cast<uint4*>(out + (size_t)i * 8) = v;
+}
+
+void launch_fragpack(const void* w, int Cout, int K, void* out, hipStream_t st) {
+    const long n = (long)Cout * K / 8;
+    hipLaunchKernelGGL(fragpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const bf16_t*>(w), Cout, K,
+                       static_cast<bf16_t*>(out));
+}
+
+bool bneck_wide_fusable(const BneckWideArgs& a) { return a.Cin == WCIN && a.Cmid == WC && a.H == WHW && a.W == WHW && a.fa && a.fb && a.fc; }
+
+void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st) {
+    ConvArgs d{};
+    d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
+    void* tok = prof_begin(d, 2, st);
+    hipLaunchKernelGGL(bneck256_kernel, dim3(a.B), dim3(512), 0, st, a);
+    prof_end(tok, st);
+}
+
+}  // namespace ivosw

@@ -43,6 +43,20 @@ void prof_end(void* tok, hipStream_t st);
 bool bneck_fusable(const BneckArgs& a);
 void launch_bneck(const BneckArgs& a, hipStream_t st);
 
+// one whole identity bottleneck of a wide stage (res4: 16x16 frames, 1024 -> 256 -> 256 -> 1024), bf16, one frame per
+// workgroup, weights pre-arranged in MFMA-operand order (bottleneck_wide.hip)
+struct BneckWideArgs {
+    const void* x;       // NHWC [B,H,W,Cin]; also the residual
+    void* y;             // NHWC [B,H,W,Cin]
+    const void* fa; const float* ba;   // conv1 [Cmid][Cin]     in fragment order (launch_fragpack)
+    const void* fb; const float* bb;   // conv2 [Cmid][9*Cmid]
+    const void* fc; const float* bc;   // conv3 [Cin][Cmid]
+    int B, H, W, Cin, Cmid;
+};
+bool bneck_wide_fusable(const BneckWideArgs& a);
+void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st);
+void launch_fragpack(const void* w, int Cout, int K, void* out, hipStream_t st);
+
 // runtime tunables (capi.cpp): value of IVOSW_TUNE_<KEY> from the environment unless ivosw_tune_set() overrode it
 int tune_get(const char* key, int dflt);
 void launch_pack_conv(const float* w, const float* g, const float* b, const float* rm, const float* rv, int Cout, int Cin,

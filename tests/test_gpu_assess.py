@@ -140,6 +140,30 @@ def test_fused_bottleneck_matches_layerwise(dev, net16, net32):
         lib.ivosw_tune_set(b"FUSE", 1)
 
 
+def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
+    """bf16 mode: res4's identity blocks as one frame-per-workgroup kernel with fragment-ordered, wave-private weights
+    (tunable FUSE_WIDE=1, default) against the three layer kernels: same bf16 roundings of t1 / t2 / block outputs,
+    different fp32 accumulation order."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge in ((8, True), (3, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        try:
+            lib.ivosw_tune_set(b"FUSE_WIDE", 1)
+            _, a = net16.forward_tap(ttf, ttp, "res4")
+            sa = net16(ttf, ttp).cpu().numpy()
+            lib.ivosw_tune_set(b"FUSE_WIDE", 0)
+            _, b = net16.forward_tap(ttf, ttp, "res4")
+            sb = net16(ttf, ttp).cpu().numpy()
+        finally:
+            lib.ivosw_tune_set(b"FUSE_WIDE", 1)
+        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= 2e-2 * scale, np.abs(a - b).max() / scale
+        np.testing.assert_allclose(a.mean(), b.mean(), rtol=2e-3)
+        np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
+
+
 def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
     """bf16 mode: the 3x3 stride-1 layers with the halo patch LDS-resident (tunable PATCH3=1, default) against the
     per-tap implicit-GEMM kernel (PATCH3=0): same operands, same K order inside a tap, different accumulation order
