@@ -138,6 +138,12 @@ int ivosw_bneck_probe(const void* x, void* y, const void* wa, const float* ba, c
                       int B, int H, int W, int Cin, int Cmid,
                       unsigned long long* ts, ivosw_stream_t stream);
 
+/* Tuning probe: ONE wide fused bottleneck (res4 identity block: H = W = 16, Cin = 1024, Cmid = 256), weights K-major
+ * packed bf16; `frag` is device scratch for their fragment-ordered copies; ts [B][8] uint64 phase stamps or NULL.   */
+int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, const float* ba, const void* wb, const float* bb,
+                           const void* wc, const float* bc, void* frag, int B, int H, int W, int Cin, int Cmid,
+                           unsigned long long* ts, ivosw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

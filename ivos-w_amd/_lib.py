@@ -40,6 +40,7 @@ SIGNATURES = {
     "ivosw_profile_report": (_i, [C.c_char_p, _sz]),
     "ivosw_tune_set": (_i, [C.c_char_p, _i]),
     "ivosw_bneck_probe": (_i, [_p] * 11 + [_i] * 5 + [_p, _p]),
+    "ivosw_bneck_wide_probe": (_i, [_p] * 9 + [_i] * 5 + [_p, _p]),
 }
 
 _lib = None

@@ -59,6 +59,10 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
     const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * WNPX * WCIN;
     bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * WNPX * WCIN;
 
+    auto stamp = [&](int k) {
+        if (p.ts && tid == 0) p.ts[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     f32x16 acc[8];                                   // [pixel tile] for this wave's channel tile
     auto zero_acc = [&]() {
 #pragma unroll
@@ -148,7 +152,9 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    stamp(1);
     store_img(p.ba);
+    stamp(2);
 
     // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x 4 slices
     {
@@ -216,7 +222,9 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
         __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
         asm volatile("" ::: "memory");
     }
+    stamp(3);
     store_img(p.bb);
+    stamp(4);
 
     // ================================================================ phase C: y = relu(Wc t2 + bc + x), 4 chunks of 256 channels
     {
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
                     if (ks < 3) rd(ks + 1, 1);
                 }
             }
+            if (chunk == 3) stamp(5);
             // store pass, one pixel tile at a time through the wave's 4-KB staging tile [32 px][32 ch] fp32 (16-B slots
             // XOR-swizzled by the pixel row): + residual -> ReLU -> bf16 -> 64-B row segments
             const size_t cofs = (size_t)ct * 32 + 8 * u;
@@ -304,6 +313,7 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
                 if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
             }
         }
+        stamp(6);
     }
 }
 
@@ -338,3 +348,25 @@ void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st) {
 }
 
 }  // namespace ivosw
+
+// Tuning probe: one wide fused bottleneck launch (weights given K-major packed; fragment-ordered copies are made into
+// `frag`, >= 2 * (Cmid*Cin + 9*Cmid*Cmid + Cin*Cmid) bytes) with phase stamps ts [B][8] (may be NULL).
+extern "C" int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, const float* ba, const void* wb, const float* bb,
+                                      const void* wc, const float* bc, void* frag, int B, int H, int W, int Cin, int Cmid,
+                                      unsigned long long* ts, ivosw_stream_t stream) {
+    using namespace ivosw;
+    IVOSW_REQUIRE(x && y && wa && ba && wb && bb && wc && bc && frag, "null pointer");
+    hipStream_t st = as_stream(stream);
+    char* f = static_cast<char*>(frag);
+    const size_t n1 = (size_t)Cmid * Cin * 2, n2 = (size_t)Cmid * 9 * Cmid * 2;
+    launch_fragpack(wa, Cmid, Cin, f, st);
+    launch_fragpack(wb, Cmid, 9 * Cmid, f + n1, st);
+    launch_fragpack(wc, Cin, Cmid, f + n1 + n2, st);
+    BneckWideArgs a{};
+    a.x = x; a.y = y; a.fa = f; a.ba = ba; a.fb = f + n1; a.bb = bb; a.fc = f + n1 + n2; a.bc = bc;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cmid = Cmid; a.ts = ts;
+    IVOSW_REQUIRE(bneck_wide_fusable(a), "shape is not covered by the wide fused bottleneck kernel");
+    launch_bneck_wide(a, st);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}

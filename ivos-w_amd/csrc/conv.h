@@ -52,6 +52,7 @@ struct BneckWideArgs {
     const void* fb; const float* bb;   // conv2 [Cmid][9*Cmid]
     const void* fc; const float* bc;   // conv3 [Cin][Cmid]
     int B, H, W, Cin, Cmid;
+    unsigned long long* ts;            // optional [B][8] s_memtime stamps at the phase boundaries (ivosw_bneck_wide_probe)
 };
 bool bneck_wide_fusable(const BneckWideArgs& a);
 void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st);
