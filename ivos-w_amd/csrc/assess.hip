@@ -23,7 +23,7 @@ struct ConvPlan {
 struct BlockPlan {
     int c1, c2, c3, ds;  // indices into convs (ds = -1 if none)
     size_t cat_w_off, cat_b_off;  // first blocks: conv3 | downsample concatenated along K, bias sum (conv3 absorbs the downsample conv)
-    size_t f1_off, f2_off, f3_off;  // bf16, res4 identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
+    size_t f1_off, f2_off, f3_off;  // bf16, res4 / res5 identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
 };
 
 struct Plan {
@@ -71,7 +71,7 @@ static Plan make_plan(int dtype) {
             if (b == 0) {
                 bp.cat_w_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
                 bp.cat_b_off = take((size_t)planes[s] * 4 * sizeof(float));
-            } else if (dtype == IVOSW_BF16 && s == 2) {
+            } else if (dtype == IVOSW_BF16 && s >= 2) {
                 bp.f1_off = take((size_t)planes[s] * inpl * es);
                 bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
                 bp.f3_off = take((size_t)planes[s] * 4 * planes[s] * es);

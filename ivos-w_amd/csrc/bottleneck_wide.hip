@@ -1,5 +1,5 @@
-// Whole-bottleneck fusion for the wide stages (bf16): res4's identity blocks (C = 256, 16x16 frames, 1024 -> 256 ->
-// 256 (3x3) -> 1024 + residual).
+// Whole-bottleneck fusion for the wide stages (bf16): the identity blocks of res4 (C = 256, 16x16 frames, 1024 -> 256 ->
+// 256 (3x3) -> 1024 + residual, one frame per workgroup) and res5 (C = 512, 8x8 frames, two frames per workgroup).
 //
 // Reference arithmetic: torchvision ResNet-50 v1.5 Bottleneck as Encoder.forward runs it (models/assessment.py:60),
 //     out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x),  BN folded into weights + bias.
@@ -27,12 +27,7 @@
 namespace ivosw {
 
 namespace {
-constexpr int WC = 256, WCIN = 1024, WHW = 16, WNPX = WHW * WHW;   // res4 identity block
-constexpr int SLICE = WNPX * ROWB;                                   // 32 KB: one 64-channel slice of a 256-pixel image
-constexpr int IMG_BYTES = 4 * SLICE;                                 // 128 KB
-constexpr int STG_OFF = IMG_BYTES;                                   // 8 x 4 KB
-constexpr int WIDE_LDS = IMG_BYTES + 8 * 4096;
-static_assert(WIDE_LDS == 163840, "LDS map");
+constexpr int WIDE_LDS = 163840;
 
 // one MFMA weight operand of the fragment-ordered copy: channel tile ct, k-step ks of KS per tile
 __device__ __forceinline__ const uint4* wfrag(const void* base, int ct, int KS, int ks, int lane) {
@@ -49,50 +44,67 @@ __device__ __forceinline__ void lgkm_wait() {
 }
 }  // namespace
 
-__global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
+// C = mid width (256: res4, 512: res5), HW = frame edge (16 / 8), FR = frames per workgroup (1 / 2): C * FR * HW^2 * 2 B
+// = 128 KB of t1 / t2 either way, and every wave owns CPW channel tiles x NPT pixel tiles = 8 accumulator tiles.
+template <int C, int HW, int FR>
+__global__ __launch_bounds__(512) void bneck_wide_kernel(BneckWideArgs p) {
+    constexpr int CIN = 4 * C, NPX = FR * HW * HW, NPT = NPX / 32, NCT = C / 32, CPW = NCT / 8, NSL = C / 64;
+    constexpr int SLICE = NPX * ROWB;                // one 64-channel slice of the pixel image
+    constexpr int IMG_BYTES = NSL * SLICE, STG_OFF = IMG_BYTES;
+    constexpr int HP = NPT / 2;                      // pixel tiles per rolling half
+    static_assert(IMG_BYTES == 131072 && CPW * NPT == 8 && IMG_BYTES + 8 * 4096 == WIDE_LDS, "tile geometry");
+    static_assert(4 * SLICE <= IMG_BYTES, "x ring: 4 slots");
     __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];   // the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhalf = lane >> 5;
-    const int b = blockIdx.x;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * WNPX * WCIN;
-    bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * WNPX * WCIN;
+    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)blockIdx.x * NPX * CIN;
+    bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)blockIdx.x * NPX * CIN;
 
     auto stamp = [&](int k) {
         if (p.ts && tid == 0) p.ts[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    f32x16 acc[8];                                   // [pixel tile] for this wave's channel tile
+    if (tid < 32) *reinterpret_cast<unsigned*>(lds + STG_OFF + tid * 4) = 0u;   // the zero row of phase B (visible after phase A's barriers)
+    f32x16 acc[8];                                   // [channel tile c of the wave][pixel tile i] at c * NPT + i
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     };
-    // pixel-operand fragment reads in two rolling halves (pixel tiles 0-3 / 4-7): the half just consumed is re-read
-    // for the next k-step while the other half's four MFMAs run
-    u32x4 pf[8];
-
-    // ================================================================ phase A: t1 = relu(Wa x + ba), K = 1024
-    {
-        constexpr int NK = WCIN / 64;                // 16 K-tiles of x through a 4-slot ring; wave-private Wa fragments
-        const int rsub = lane >> 3, cpos = lane & 7;
-        const bf16_t* xsrc[4];
+    // pixel-operand fragment reads in two rolling halves of the pixel tiles: the half just consumed is re-read for the
+    // next k-step while the other half's MFMAs run
+    u32x4 pf[NPT];
+    auto mm_half = [&](const u32x4 (&w)[CPW], int half) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (wave * 4 + i) * 8 + rsub;
-            xsrc[i] = X + (size_t)row * WCIN + (cpos ^ ((row >> 1) & 7)) * 8;
+        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int i = 0; i < HP; ++i) acc[c * NPT + half * HP + i] = mfma_bf16(w[c], pf[half * HP + i], acc[c * NPT + half * HP + i]);
+    };
+
+    // ================================================================ phase A: t1 = relu(Wa x + ba), K = CIN
+    {
+        constexpr int NK = CIN / 64, XG = NPX / 64;  // K-tiles of x through a 4-slot ring, XG 1-KB row groups per wave and tile
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const bf16_t* xsrc[XG];
+#pragma unroll
+        for (int i = 0; i < XG; ++i) {
+            const int row = (wave * XG + i) * 8 + rsub;
+            xsrc[i] = X + (size_t)row * CIN + (cpos ^ ((row >> 1) & 7)) * 8;
         }
         auto issue_x = [&](int kt) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dma16(xsrc[i] + kt * 64, lds + (kt & 3) * SLICE + (wave * 4 + i) * 1024);
+            for (int i = 0; i < XG; ++i) dma16(xsrc[i] + kt * 64, lds + (kt & 3) * SLICE + (wave * XG + i) * 1024);
         };
-        u32x4 wq[2][4];                              // weight fragments of two K-tiles (inline-asm loads: counted by hand
+        u32x4 wq[2][4][CPW];                         // weight fragments of two K-tiles (inline-asm loads: counted by hand
         auto load_w = [&](int kt, int set) {         // next to the LDS-DMA queue, hipcc would drain it at every use)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, wave, WCIN / 16, kt * 4 + ks, lane)) : "memory");
+#pragma unroll
+                for (int c = 0; c < CPW; ++c)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks][c]) : "v"(wfrag(p.fa, wave * CPW + c, CIN / 16, kt * 4 + ks, lane)) : "memory");
         };
         zero_acc();
         // queue per wave: W0 X0 X1 | iter kt: W(kt+1) X(kt+2) -> at the top of iter kt only X(kt+1) is younger than W(kt)
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
 #pragma unroll
         for (int par = 0; par < 2; ++par) {          // par == kt & 1: register-set index is a compile-time constant
             const int kt = kt2 + par;
-            if (kt + 1 < NK) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            if (kt + 1 < NK) wait_vmcnt<XG>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();            // x tile kt landed for every wave; tile kt-1 is done: slot (kt+2)&3 is free
             asm volatile("" ::: "memory");
             if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
@@ -112,40 +124,42 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
             auto rd = [&](int ks, int half) {
                 const int ch = 2 * ks + lhalf;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(xb + swz((half * 4 + i) * 32 + lrow, ch));
+                for (int i = 0; i < HP; ++i) pf[half * HP + i] = lds_read_b128(xb + swz((half * HP + i) * 32 + lrow, ch));
             };
             rd(0, 0);
             rd(0, 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const u32x4 w = wq[par][ks];
-                lgkm_wait<4>();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                lgkm_wait<HP>();
+                mm_half(wq[par][ks], 0);
                 if (ks < 3) rd(ks + 1, 0);
-                if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
-#pragma unroll
-                for (int i = 4; i < 8; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                if (ks < 3) lgkm_wait<HP>(); else lgkm_wait<0>();
+                mm_half(wq[par][ks], 1);
                 if (ks < 3) rd(ks + 1, 1);
             }
         }
         __builtin_amdgcn_s_barrier();                // every wave is done with the ring: its space becomes t1
         asm volatile("" ::: "memory");
     }
-    // accumulators -> relu(acc + bias) -> bf16 -> image slice (wave >> 1), chunks 4*(wave & 1) + g
+    // accumulators -> relu(acc + bias) -> bf16 -> image: channel tile ct lives in slice ct >> 1, chunks 4 * (ct & 1) + g
     auto store_img = [&](const float* bias) {
-        float4 bq[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bias + wave * 32 + 8 * g + 4 * lhalf);
+        for (int c = 0; c < CPW; ++c) {
+            const int ct = wave * CPW + c;
+            float4 bq[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int px = i * 32 + lrow;
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bias + ct * 32 + 8 * g + 4 * lhalf);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 pk;
-                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
-                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
-                lds_write_b64(lds_base + (wave >> 1) * SLICE + px * ROWB + ((((wave & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+            for (int i = 0; i < NPT; ++i) {
+                const int px = i * 32 + lrow;
+                const f32x16& a = acc[c * NPT + i];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk;
+                    pk.x = pack2_bf16(fmaxf(a[4 * g] + bq[g].x, 0.f), fmaxf(a[4 * g + 1] + bq[g].y, 0.f));
+                    pk.y = pack2_bf16(fmaxf(a[4 * g + 2] + bq[g].z, 0.f), fmaxf(a[4 * g + 3] + bq[g].w, 0.f));
+                    lds_write_b64(lds_base + (ct >> 1) * SLICE + px * ROWB + ((((ct & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                }
             }
         }
         lds_wait();
@@ -156,65 +170,71 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
     store_img(p.ba);
     stamp(2);
 
-    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x 4 slices
+    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x NSL slices
     {
         zero_acc();
-        // this lane's pixel in each tile: y = 2*tile + (lrow >> 4), x = lrow & 15
-        const int px_x = lrow & 15, px_yo = lrow >> 4;
-        uint4 wn[4], wc[4];
+        constexpr int KSB = 9 * C / 16;
+        // this lane's pixel in tile i: index i*32 + lrow -> (frame, y, x)
+        int pyy[NPT], pxx[NPT], pfr[NPT];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, wave, 9 * WC / 16, ks, lane);
+        for (int i = 0; i < NPT; ++i) {
+            const int q = i * 32 + lrow;
+            pfr[i] = q / (HW * HW);
+            pyy[i] = (q / HW) % HW;
+            pxx[i] = q % HW;
+        }
+        uint4 wn[4][CPW];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) wn[ks][c] = *wfrag(p.fb, wave * CPW + c, KSB, ks, lane);
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
-            const bool vx = (unsigned)(px_x + kx) < (unsigned)WHW;
-            // shifted source row of this lane in every pixel tile (invalid lanes read a clamped row and get zeros)
-            unsigned roff[8];                        // byte offset of the row; its swizzle key is (row >> 1) & 7 = (roff >> 8) & 7
+            // shifted source row of this lane in every pixel tile; the 3x3's zero padding: out-of-frame lanes read a
+            // 128-B row of zeros parked in the (still unused) store-staging area instead of being masked afterwards
+            unsigned roff[NPT];                      // byte offset of the row; its swizzle key is (row >> 1) & 7 = (roff >> 8) & 7
             unsigned vmask = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int y = 2 * i + px_yo + ky;
-                const bool ok = vx && (unsigned)y < (unsigned)WHW;
-                const int q = ok ? y * WHW + px_x + kx : 0;
-                roff[i] = q * ROWB;
+            for (int i = 0; i < NPT; ++i) {
+                const int y = pyy[i] + ky, x = pxx[i] + kx;
+                const bool ok = (unsigned)y < (unsigned)HW && (unsigned)x < (unsigned)HW;
+                roff[i] = ok ? ((pfr[i] * HW + y) * HW + x) * ROWB : STG_OFF;
                 vmask |= ok ? (1u << i) : 0u;
             }
 #pragma unroll 1
-            for (int sl = 0; sl < 4; ++sl) {
+            for (int sl = 0; sl < NSL; ++sl) {
+                u32x4 wc[4][CPW];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wc[ks] = wn[ks];
-                const int nstep = (tap * 4 + sl + 1) * 4;       // next (tap, slice)'s fragments: in flight under this one's MFMAs
-                if (nstep < 9 * WC / 16) {
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, wave, 9 * WC / 16, nstep + ks, lane);
+                    for (int c = 0; c < CPW; ++c) wc[ks][c] = as_u32x4(wn[ks][c]);
+                const int nstep = (tap * NSL + sl + 1) * 4;     // next (tap, slice)'s fragments: in flight under this one's MFMAs
+                if (nstep < KSB) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int c = 0; c < CPW; ++c) wn[ks][c] = *wfrag(p.fb, wave * CPW + c, KSB, nstep + ks, lane);
                 }
-                const unsigned tb = lds_base + sl * SLICE;
+                unsigned rowa[NPT];                  // row address in slice sl (the zero row is not per slice)
+#pragma unroll
+                for (int t = 0; t < NPT; ++t) rowa[t] = lds_base + roff[t] + (((vmask >> t) & 1u) ? sl * SLICE : 0);
                 auto rd = [&](int ks, int half) {
                     const int ch = 2 * ks + lhalf;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int t = half * 4 + i;
-                        pf[t] = lds_read_b128(tb + roff[t] + ((ch ^ ((roff[t] >> 8) & 7)) << 4));
-                    }
-                };
-                auto mm = [&](const u32x4 w, int half) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int t = half * 4 + i;
-                        u32x4 v = pf[t];
-                        if (!((vmask >> t) & 1u)) v = u32x4{0, 0, 0, 0};
-                        acc[t] = mfma_bf16(w, v, acc[t]);
+                    for (int i = 0; i < HP; ++i) {
+                        const int t = half * HP + i;
+                        pf[t] = lds_read_b128(rowa[t] + ((ch ^ ((roff[t] >> 8) & 7)) << 4));
                     }
                 };
                 rd(0, 0);
                 rd(0, 1);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const u32x4 w = as_u32x4(wc[ks]);
-                    lgkm_wait<4>();
-                    mm(w, 0);
+                    lgkm_wait<HP>();
+                    mm_half(wc[ks], 0);
                     if (ks < 3) rd(ks + 1, 0);
-                    if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
-                    mm(w, 1);
+                    if (ks < 3) lgkm_wait<HP>(); else lgkm_wait<0>();
+                    mm_half(wc[ks], 1);
                     if (ks < 3) rd(ks + 1, 1);
                 }
             }
@@ -226,76 +246,88 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
     store_img(p.bb);
     stamp(4);
 
-    // ================================================================ phase C: y = relu(Wc t2 + bc + x), 4 chunks of 256 channels
+    // ================================================================ phase C: y = relu(Wc t2 + bc + x), 4 chunks of 8*CPW channel tiles
     {
+        constexpr int KSC = C / 16, NCH = (CIN / 32) / (8 * CPW), NSTEP = NCH * NSL;
+        static_assert(NCH == 4, "four output chunks");
         float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
-        const int u = lane & 3, prr = lane >> 2;     // store pass: 8-channel group u of the wave's 32 channels, pixel sub-row prr
-        uint4 wn[4];
+        const int u = lane & 3, prr = lane >> 2;     // store pass: 8-channel group u of a 32-channel tile, pixel sub-row prr
+        uint4 wn[4][CPW];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, WC / 16, ks, lane);
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) wn[ks][c] = *wfrag(p.fc, wave * CPW + c, KSC, ks, lane);
 #pragma unroll 1
-        for (int chunk = 0; chunk < 4; ++chunk) {
-            const int ct = chunk * 8 + wave;         // output channel tile of this wave in this chunk
-            {
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const int ct0 = (chunk * 8 + wave) * CPW;        // first output channel tile of this wave in this chunk
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
                 float4 bq[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bc + ct * 32 + 8 * g + 4 * lhalf);
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bc + (ct0 + c) * 32 + 8 * g + 4 * lhalf);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < NPT; ++i)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+                        f32x16& a = acc[c * NPT + i];
+                        a[4 * g] = bq[g].x; a[4 * g + 1] = bq[g].y; a[4 * g + 2] = bq[g].z; a[4 * g + 3] = bq[g].w;
                     }
             }
 #pragma unroll 1
-            for (int sl = 0; sl < 4; ++sl) {         // K = 256: slice sl of t2, 4 k-steps each
-                uint4 wc[4];
+            for (int sl = 0; sl < NSL; ++sl) {       // K = C: slice sl of t2, 4 k-steps each
+                u32x4 wc[4][CPW];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wc[ks] = wn[ks];
-                const int nxt = chunk * 4 + sl + 1;  // next (chunk, slice): channel tile (nxt >> 2) * 8 + wave, k-steps (nxt & 3) * 4 ..
-                if (nxt < 16) {
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, (nxt >> 2) * 8 + wave, WC / 16, (nxt & 3) * 4 + ks, lane);
+                    for (int c = 0; c < CPW; ++c) wc[ks][c] = as_u32x4(wn[ks][c]);
+                const int nxt = chunk * NSL + sl + 1;        // next (chunk, slice)
+                if (nxt < NSTEP) {
+                    const int nct0 = ((nxt / NSL) * 8 + wave) * CPW, nks = (nxt % NSL) * 4;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int c = 0; c < CPW; ++c) wn[ks][c] = *wfrag(p.fc, nct0 + c, KSC, nks + ks, lane);
                 }
                 const unsigned tb = lds_base + sl * SLICE;
                 auto rd = [&](int ks, int half) {
                     const int ch = 2 * ks + lhalf;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(tb + swz((half * 4 + i) * 32 + lrow, ch));
+                    for (int i = 0; i < HP; ++i) pf[half * HP + i] = lds_read_b128(tb + swz((half * HP + i) * 32 + lrow, ch));
                 };
                 rd(0, 0);
                 rd(0, 1);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const u32x4 w = as_u32x4(wc[ks]);
-                    lgkm_wait<4>();
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                    lgkm_wait<HP>();
+                    mm_half(wc[ks], 0);
                     if (ks < 3) rd(ks + 1, 0);
-                    if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
-#pragma unroll
-                    for (int i = 4; i < 8; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                    if (ks < 3) lgkm_wait<HP>(); else lgkm_wait<0>();
+                    mm_half(wc[ks], 1);
                     if (ks < 3) rd(ks + 1, 1);
                 }
             }
-            if (chunk == 3) stamp(5);
-            // store pass, one pixel tile at a time through the wave's 4-KB staging tile [32 px][32 ch] fp32 (16-B slots
-            // XOR-swizzled by the pixel row): + residual -> ReLU -> bf16 -> 64-B row segments
-            const size_t cofs = (size_t)ct * 32 + 8 * u;
+            if (chunk == NCH - 1) stamp(5);
+            // store pass, one (channel tile, pixel tile) at a time through the wave's 4-KB staging tile [32 px][32 ch] fp32
+            // (16-B slots XOR-swizzled by the pixel row): + residual -> ReLU -> bf16 -> 64-B row segments
             uint4 rr[2];
 #pragma unroll
-            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + (size_t)(it * 16 + prr) * WCIN + cofs);
+            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + (size_t)(it * 16 + prr) * CIN + (size_t)ct0 * 32 + 8 * u);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int item = 0; item < 8; ++item) {
+                const int c = item / NPT, i = item % NPT;
+                const size_t cofs = (size_t)(ct0 + c) * 32 + 8 * u;
+                const f32x16& a = acc[item];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int slot = (2 * g + lhalf) ^ (lrow & 7);
-                    *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                    *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
                 }
                 uint4 rn[2];
-                if (i < 7) {
+                if (item < 7) {
+                    const int c1 = (item + 1) / NPT, i1 = (item + 1) % NPT;
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) rn[it] = *reinterpret_cast<const uint4*>(X + (size_t)((i + 1) * 32 + it * 16 + prr) * WCIN + cofs);
+                    for (int it = 0; it < 2; ++it)
+                        rn[it] = *reinterpret_cast<const uint4*>(X + (size_t)(i1 * 32 + it * 16 + prr) * CIN + (size_t)(ct0 + c1) * 32 + 8 * u);
                 }
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
@@ -308,9 +340,9 @@ __global__ __launch_bounds__(512) void bneck256_kernel(BneckWideArgs p) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
-                    *reinterpret_cast<uint4*>(Y + (size_t)(i * 32 + pr) * WCIN + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    *reinterpret_cast<uint4*>(Y + (size_t)(i * 32 + pr) * CIN + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
-                if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
+                if (item < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
             }
         }
         stamp(6);
@@ -337,13 +369,20 @@ void launch_fragpack(const void* w, int Cout, int K, void* out, hipStream_t st) 
                        static_cast<bf16_t*>(out));
 }
 
-bool bneck_wide_fusable(const BneckWideArgs& a) { return a.Cin == WCIN && a.Cmid == WC && a.H == WHW && a.W == WHW && a.fa && a.fb && a.fc; }
+bool bneck_wide_fusable(const BneckWideArgs& a) {
+    if (!a.fa || !a.fb || !a.fc || a.Cin != 4 * a.Cmid || a.H != a.W) return false;
+    // res5 (Cmid 512, 8x8 frames, two per workgroup) is instantiated and correct but NOT used: 8.7 MB of weights per
+    // 128-pixel workgroup and only B/2 workgroups make it slower (240 us) than the three layer kernels (201 us)
+    if (a.Cmid == 512 && a.H == 8 && a.B % 2 == 0) return tune_get("FUSE_WIDE5", 0) != 0;
+    return a.Cmid == 256 && a.H == 16;
+}
 
 void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st) {
     ConvArgs d{};
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
     void* tok = prof_begin(d, 2, st);
-    hipLaunchKernelGGL(bneck256_kernel, dim3(a.B), dim3(512), 0, st, a);
+    if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 2>), dim3(a.B / 2), dim3(512), 0, st, a);
     prof_end(tok, st);
 }
 

@@ -141,27 +141,29 @@ def test_fused_bottleneck_matches_layerwise(dev, net16, net32):
 
 
 def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
-    """bf16 mode: res4's identity blocks as one frame-per-workgroup kernel with fragment-ordered, wave-private weights
-    (tunable FUSE_WIDE=1, default) against the three layer kernels: same bf16 roundings of t1 / t2 / block outputs,
-    different fp32 accumulation order."""
+    """bf16 mode: the identity blocks of res4 (one 16x16 frame per workgroup) and res5 (two 8x8 frames per workgroup; an
+    odd batch falls back to the layer kernels) as ONE kernel with fragment-ordered, wave-private weights (tunable
+    FUSE_WIDE=1, default) against the three layer kernels: same bf16 roundings of t1 / t2 / block outputs, different
+    fp32 accumulation order."""
     from ivos_w_amd import _lib as L
     lib = L.lib()
     for B, edge in ((8, True), (3, False)):
         _, _, ttf, ttp = inputs(dev, B, edge)
-        try:
-            lib.ivosw_tune_set(b"FUSE_WIDE", 1)
-            _, a = net16.forward_tap(ttf, ttp, "res4")
-            sa = net16(ttf, ttp).cpu().numpy()
-            lib.ivosw_tune_set(b"FUSE_WIDE", 0)
-            _, b = net16.forward_tap(ttf, ttp, "res4")
-            sb = net16(ttf, ttp).cpu().numpy()
-        finally:
-            lib.ivosw_tune_set(b"FUSE_WIDE", 1)
-        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
-        scale = np.abs(b).max()
-        assert np.abs(a - b).max() <= 2e-2 * scale, np.abs(a - b).max() / scale
-        np.testing.assert_allclose(a.mean(), b.mean(), rtol=2e-3)
-        np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
+        for nm in ("res4", "res5"):
+            try:
+                lib.ivosw_tune_set(b"FUSE_WIDE", 1)
+                _, a = net16.forward_tap(ttf, ttp, nm)
+                sa = net16(ttf, ttp).cpu().numpy()
+                lib.ivosw_tune_set(b"FUSE_WIDE", 0)
+                _, b = net16.forward_tap(ttf, ttp, nm)
+                sb = net16(ttf, ttp).cpu().numpy()
+            finally:
+                lib.ivosw_tune_set(b"FUSE_WIDE", 1)
+            a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+            scale = np.abs(b).max()
+            assert np.abs(a - b).max() <= 2e-2 * scale, (nm, np.abs(a - b).max() / scale)
+            np.testing.assert_allclose(a.mean(), b.mean(), rtol=2e-3, err_msg=nm)
+            np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
 
 
 def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
