@@ -23,7 +23,7 @@ struct ConvPlan {
 struct BlockPlan {
     int c1, c2, c3, ds;  // indices into convs (ds = -1 if none)
     size_t cat_w_off, cat_b_off;  // first blocks: conv3 | downsample concatenated along K, bias sum (conv3 absorbs the downsample conv)
-    size_t f1_off, f2_off, f3_off;  // bf16, res4 / res5 identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
+    size_t f1_off, f2_off, f3_off;  // bf16, res3 / res4 / res5 identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
 };
 
 struct Plan {
@@ -71,7 +71,7 @@ static Plan make_plan(int dtype) {
             if (b == 0) {
                 bp.cat_w_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
                 bp.cat_b_off = take((size_t)planes[s] * 4 * sizeof(float));
-            } else if (dtype == IVOSW_BF16 && s >= 2) {
+            } else if (dtype == IVOSW_BF16 && s >= 1) {
                 bp.f1_off = take((size_t)planes[s] * inpl * es);
                 bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
                 bp.f3_off = take((size_t)planes[s] * 4 * planes[s] * es);
@@ -262,7 +262,7 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
             }
             if (dtype == IVOSW_BF16 && bp.f1_off && tune_get("FUSE_WIDE", 1)) {
                 BneckWideArgs q{};
-                q.x = x; q.y = y;
+                q.x = x; q.y = y; q.zeros = base + P.zero_off;
                 q.fa = base + bp.f1_off; q.ba = reinterpret_cast<const float*>(base + c1.b_off);
                 q.fb = base + bp.f2_off; q.bb = reinterpret_cast<const float*>(base + c2.b_off);
                 q.fc = base + bp.f3_off; q.bc = reinterpret_cast<const float*>(base + c3.b_off);

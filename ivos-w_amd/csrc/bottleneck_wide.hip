@@ -349,6 +349,301 @@ __global__ __launch_bounds__(512) void bneck_wide_kernel(BneckWideArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- res3 identity blocks: 32x32 frames, 512 -> 128 -> 128 -> 512
+// Same dataflow (wave-private fragment-ordered weights, t1 / t2 in LDS, transposed MFMAs), but the frame does not fit
+// one workgroup: a workgroup owns a 16x16-pixel tile and phase A computes t1 on its 18x18 halo (352 rows = 11 pixel
+// tiles, zeros stored for halo pixels outside the frame, so phase B needs no padding logic).
+//   phase A  44 (channel tile, pixel tile) accumulators: wave = (channel tile w & 3, pixel tiles 0-5 | 6-10)
+//   phase B  32 tiles: wave = (channel tile w & 3, pixel tiles 0-3 | 4-7), shifted rows hb + ky*18 + kx of the halo image
+//   phase C  2 chunks x (8 channel tiles = 8 waves) x 8 pixel tiles, store pass as in the frame kernel
+// LDS: [0, 125952) x ring (3 slots of 41 row groups) -> t1 (2 slices x 352 rows) -> t2 (2 x 256 rows); staging at 128 KB.
+__global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
+    constexpr int C = 128, CIN = 512, HW = 32, BT = 16, HT = 18, HR = HT * HT, MH = 352, NGA = 41;
+    constexpr int SLOT = NGA * 1024;                 // 41984 B per x K-tile
+    constexpr int T1S = MH * ROWB, T2S = 256 * ROWB; // slice sizes of the t1 / t2 images
+    constexpr int STG_OFF = 131072;
+    static_assert(3 * SLOT <= STG_OFF && 2 * T1S <= STG_OFF && 2 * SLOT + 8192 + MH * ROWB <= WIDE_LDS, "LDS map");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = L >> 2, tl = L & 3;
+    const int y0 = (tl >> 1) * BT, x0 = (tl & 1) * BT;
+    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * HW * HW * CIN;
+    bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * HW * HW * CIN;
+    const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
+    const int ct4 = wave & 3, grp = wave >> 2;
+
+    // ================================================================ phase A: t1 = relu(Wa x + ba) on the halo, K = 512
+    {
+        constexpr int NK = CIN / 64;
+        f32x16 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const int np = (NGA - wave + 7) / 8;         // row groups of this wave: wave, wave+8, ... (6 for wave 0, else 5)
+        const bf16_t* xsrc[6];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int g = wave + 8 * i;
+            const int hr = g * 8 + rsub;
+            const int hy = hr / HT, hx = hr - hy * HT;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NGA && hr < HR && y >= 0 && y < HW && x >= 0 && x < HW;
+            xsrc[i] = ok ? X + ((size_t)y * HW + x) * CIN + (cpos ^ ((hr >> 1) & 7)) * 8 : zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        auto issue_x = [&](int kt) {
+            unsigned char* sb = lds + (kt % 3) * SLOT;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int g = wave + 8 * i;
+                if (g < NGA) dma16(xsrc[i] + (((okmask >> i) & 1u) ? kt * 64 : 0), sb + g * 1024);
+            }
+        };
+        u32x4 wq[2][4];
+        auto load_w = [&](int kt, int set) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, ct4, CIN / 16, kt * 4 + ks, lane)) : "memory");
+        };
+        const int pt0 = grp * 6;                     // pixel tiles pt0 .. pt0 + npt - 1
+        const bool six = grp == 0;                   // group 0 has 6 tiles, group 1 has 5 (tile 10 is the last)
+        load_w(0, 0);
+        issue_x(0);
+        issue_x(1);
+        for (int kt2 = 0; kt2 < NK; kt2 += 2)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int kt = kt2 + par;
+            if (kt + 1 < NK) wait_vmcnt_n(np); else wait_vmcnt<0>();   // only X(kt+1) is younger than W(kt)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
+            if (kt + 2 < NK) issue_x(kt + 2);        // slot (kt+2) % 3 == slot of tile kt-1: done for every wave
+            const unsigned xb = lds_base + (kt % 3) * SLOT;
+            u32x4 pf[6];
+            auto rd = [&](int ks, int half) {
+                const int ch = 2 * ks + lhalf;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int t = half * 3 + i;
+                    if (t < 5 || six) pf[t] = lds_read_b128(xb + swz((pt0 + t) * 32 + lrow, ch));
+                }
+            };
+            rd(0, 0);
+            rd(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 w = wq[par][ks];
+                if (six) lgkm_wait<3>(); else lgkm_wait<2>();
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                if (ks < 3) rd(ks + 1, 0);
+                if (ks < 3) lgkm_wait<3>(); else lgkm_wait<0>();
+                acc[3] = mfma_bf16(w, pf[3], acc[3]);
+                acc[4] = mfma_bf16(w, pf[4], acc[4]);
+                if (six) acc[5] = mfma_bf16(w, pf[5], acc[5]);
+                if (ks < 3) rd(ks + 1, 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // the ring is dead: its space becomes t1
+        asm volatile("" ::: "memory");
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.ba + ct4 * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i == 5 && !six) break;
+            const int hr = (pt0 + i) * 32 + lrow;
+            const int hy = hr / HT, hx = hr - hy * HT;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool in = y >= 0 && y < HW && x >= 0 && x < HW;
+            if (hr < HR) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk;
+                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
+                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    lds_write_b64(lds_base + (ct4 >> 1) * T1S + hr * ROWB + ((((ct4 & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                }
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x 2 slices
+    {
+        constexpr int KSB = 9 * C / 16;
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int hb[4];                                   // halo row of this lane's output pixel at tap (0,0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = (grp * 4 + i) * 32 + lrow;
+            hb[i] = (q >> 4) * HT + (q & 15);
+        }
+        uint4 wn[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ct4, KSB, ks, lane);
+#pragma unroll 1
+        for (int step = 0; step < 18; ++step) {      // step = tap * 2 + slice
+            const int tap = step >> 1, sl = step & 1;
+            u32x4 wc[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+            if (step + 1 < 18) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ct4, KSB, (step + 1) * 4 + ks, lane);
+            }
+            unsigned rowa[4], rkey[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hr = hb[i] + (tap / 3) * HT + (tap % 3);
+                rowa[i] = lds_base + sl * T1S + hr * ROWB;
+                rkey[i] = (hr >> 1) & 7;
+            }
+            u32x4 pf[4];
+            auto rd = [&](int ks, int half) {
+                const int ch = 2 * ks + lhalf;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(rowa[half * 2 + i] + ((ch ^ rkey[half * 2 + i]) << 4));
+            };
+            rd(0, 0);
+            rd(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                lgkm_wait<2>();
+                acc[0] = mfma_bf16(wc[ks], pf[0], acc[0]);
+                acc[1] = mfma_bf16(wc[ks], pf[1], acc[1]);
+                if (ks < 3) rd(ks + 1, 0);
+                if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
+                acc[2] = mfma_bf16(wc[ks], pf[2], acc[2]);
+                acc[3] = mfma_bf16(wc[ks], pf[3], acc[3]);
+                if (ks < 3) rd(ks + 1, 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
+        asm volatile("" ::: "memory");
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bb + ct4 * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = (grp * 4 + i) * 32 + lrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
+                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
+                lds_write_b64(lds_base + (ct4 >> 1) * T2S + px * ROWB + ((((ct4 & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ================================================================ phase C: y = relu(Wc t2 + bc + x), 2 chunks of 8 channel tiles
+    {
+        constexpr int KSC = C / 16;
+        f32x16 acc[8];
+        float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
+        const int u = lane & 3, prr = lane >> 2;
+        auto pix = [&](int q) { return (size_t)((y0 + (q >> 4)) * HW + x0 + (q & 15)) * CIN; };   // tile pixel q -> frame offset
+        uint4 wn[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, KSC, ks, lane);
+#pragma unroll 1
+        for (int chunk = 0; chunk < 2; ++chunk) {
+            const int ct = chunk * 8 + wave;
+            {
+                float4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bc + ct * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+                    }
+            }
+#pragma unroll 1
+            for (int sl = 0; sl < 2; ++sl) {
+                u32x4 wc[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+                const int nxt = chunk * 2 + sl + 1;
+                if (nxt < 4) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, (nxt >> 1) * 8 + wave, KSC, (nxt & 1) * 4 + ks, lane);
+                }
+                const unsigned tb = lds_base + sl * T2S;
+                u32x4 pf[8];
+                auto rd = [&](int ks, int half) {
+                    const int ch = 2 * ks + lhalf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(tb + swz((half * 4 + i) * 32 + lrow, ch));
+                };
+                rd(0, 0);
+                rd(0, 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    lgkm_wait<4>();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 0);
+                    if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
+#pragma unroll
+                    for (int i = 4; i < 8; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 1);
+                }
+            }
+            const size_t cofs = (size_t)ct * 32 + 8 * u;
+            uint4 rr[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int slot = (2 * g + lhalf) ^ (lrow & 7);
+                    *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                }
+                uint4 rn[2];
+                if (i < 7) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) rn[it] = *reinterpret_cast<const uint4*>(X + pix((i + 1) * 32 + it * 16 + prr) + cofs);
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int pr = it * 16 + prr;
+                    const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u) ^ (pr & 7)) << 2));
+                    const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u + 1) ^ (pr & 7)) << 2));
+                    const unsigned w4[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                    *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+                if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
+            }
+        }
+    }
+}
+
 // [Cout][K] K-major packed bf16 weights -> MFMA-operand order [Cout/32][K/16][64 lanes][8]: lane l of fragment (ct, ks)
 // holds row ct*32 + (l & 31), k = ks*16 + 8*(l >> 5) .. +8
 __global__ void fragpack_kernel(const bf16_t* __restrict__ w, int Cout, int K, bf16_t* __restrict__ out) {
@@ -374,6 +669,7 @@ bool bneck_wide_fusable(const BneckWideArgs& a) {
     // res5 (Cmid 512, 8x8 frames, two per workgroup) is instantiated and correct but NOT used: 8.7 MB of weights per
     // 128-pixel workgroup and only B/2 workgroups make it slower (240 us) than the three layer kernels (201 us)
     if (a.Cmid == 512 && a.H == 8 && a.B % 2 == 0) return tune_get("FUSE_WIDE5", 0) != 0;
+    if (a.Cmid == 128 && a.H == 32) return a.zeros != nullptr && tune_get("FUSE_WIDE3", 1) != 0;
     return a.Cmid == 256 && a.H == 16;
 }
 
@@ -381,7 +677,8 @@ void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st) {
     ConvArgs d{};
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
     void* tok = prof_begin(d, 2, st);
-    if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
+    if (a.Cmid == 128) hipLaunchKernelGGL(bneck_halo128_kernel, dim3(a.B * 4), dim3(512), 0, st, a);
+    else if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 2>), dim3(a.B / 2), dim3(512), 0, st, a);
     prof_end(tok, st);
 }

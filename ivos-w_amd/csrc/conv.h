@@ -51,6 +51,7 @@ struct BneckWideArgs {
     const void* fa; const float* ba;   // conv1 [Cmid][Cin]     in fragment order (launch_fragpack)
     const void* fb; const float* bb;   // conv2 [Cmid][9*Cmid]
     const void* fc; const float* bc;   // conv3 [Cin][Cmid]
+    const void* zeros;                 // >= 256 B of device zeros (halo variant)
     int B, H, W, Cin, Cmid;
     unsigned long long* ts;            // optional [B][8] s_memtime stamps at the phase boundaries (ivosw_bneck_wide_probe)
 };

@@ -149,7 +149,7 @@ def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
     lib = L.lib()
     for B, edge in ((8, True), (3, False)):
         _, _, ttf, ttp = inputs(dev, B, edge)
-        for nm in ("res4", "res5"):
+        for nm in ("res3", "res4", "res5"):
             try:
                 lib.ivosw_tune_set(b"FUSE_WIDE", 1)
                 _, a = net16.forward_tap(ttf, ttp, nm)
