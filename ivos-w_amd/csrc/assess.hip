@@ -23,7 +23,7 @@ struct ConvPlan {
 struct BlockPlan {
     int c1, c2, c3, ds;  // indices into convs (ds = -1 if none)
     size_t cat_w_off, cat_b_off;  // first blocks: conv3 | downsample concatenated along K, bias sum (conv3 absorbs the downsample conv)
-    size_t f1_off, f2_off, f3_off;  // bf16, res3 / res4 / res5 identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
+    size_t f1_off, f2_off, f3_off;  // bf16, identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
 };
 
 struct Plan {
@@ -71,7 +71,7 @@ static Plan make_plan(int dtype) {
             if (b == 0) {
                 bp.cat_w_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
                 bp.cat_b_off = take((size_t)planes[s] * 4 * sizeof(float));
-            } else if (dtype == IVOSW_BF16 && s >= 1) {
+            } else if (dtype == IVOSW_BF16) {
                 bp.f1_off = take((size_t)planes[s] * inpl * es);
                 bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
                 bp.f3_off = take((size_t)planes[s] * 4 * planes[s] * es);
@@ -243,6 +243,19 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
                 launch_conv(q, dtype, false, st);
             };
+            if (dtype == IVOSW_BF16 && bp.f1_off && tune_get("FUSE_WIDE", 1)) {
+                BneckWideArgs q{};
+                q.x = x; q.y = y; q.zeros = base + P.zero_off;
+                q.fa = base + bp.f1_off; q.ba = reinterpret_cast<const float*>(base + c1.b_off);
+                q.fb = base + bp.f2_off; q.bb = reinterpret_cast<const float*>(base + c2.b_off);
+                q.fc = base + bp.f3_off; q.bc = reinterpret_cast<const float*>(base + c3.b_off);
+                q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
+                if (bneck_wide_fusable(q)) {
+                    launch_bneck_wide(q, st);
+                    x = y;
+                    continue;
+                }
+            }
             if (dtype == IVOSW_BF16 && (bp.ds < 0 || c2.stride == 1) && tune_get("FUSE", 1)) {
                 BneckArgs q{};
                 q.x = x; q.y = y; q.zeros = base + P.zero_off;
@@ -256,19 +269,6 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
                 if (bneck_fusable(q)) {
                     launch_bneck(q, st);
-                    x = y;
-                    continue;
-                }
-            }
-            if (dtype == IVOSW_BF16 && bp.f1_off && tune_get("FUSE_WIDE", 1)) {
-                BneckWideArgs q{};
-                q.x = x; q.y = y; q.zeros = base + P.zero_off;
-                q.fa = base + bp.f1_off; q.ba = reinterpret_cast<const float*>(base + c1.b_off);
-                q.fb = base + bp.f2_off; q.bb = reinterpret_cast<const float*>(base + c2.b_off);
-                q.fc = base + bp.f3_off; q.bc = reinterpret_cast<const float*>(base + c3.b_off);
-                q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
-                if (bneck_wide_fusable(q)) {
-                    launch_bneck_wide(q, st);
                     x = y;
                     continue;
                 }

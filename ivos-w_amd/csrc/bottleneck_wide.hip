@@ -349,39 +349,46 @@ __global__ __launch_bounds__(512) void bneck_wide_kernel(BneckWideArgs p) {
     }
 }
 
-// ---------------------------------------------------------------- res3 identity blocks: 32x32 frames, 512 -> 128 -> 128 -> 512
+// ---------------------------------------------------------------- halo variant: res3 (C = 128, 32x32 frames) and res2 (C = 64, 64x64)
 // Same dataflow (wave-private fragment-ordered weights, t1 / t2 in LDS, transposed MFMAs), but the frame does not fit
 // one workgroup: a workgroup owns a 16x16-pixel tile and phase A computes t1 on its 18x18 halo (352 rows = 11 pixel
-// tiles, zeros stored for halo pixels outside the frame, so phase B needs no padding logic).
-//   phase A  44 (channel tile, pixel tile) accumulators: wave = (channel tile w & 3, pixel tiles 0-5 | 6-10)
-//   phase B  32 tiles: wave = (channel tile w & 3, pixel tiles 0-3 | 4-7), shifted rows hb + ky*18 + kx of the halo image
-//   phase C  2 chunks x (8 channel tiles = 8 waves) x 8 pixel tiles, store pass as in the frame kernel
-// LDS: [0, 125952) x ring (3 slots of 41 row groups) -> t1 (2 slices x 352 rows) -> t2 (2 x 256 rows); staging at 128 KB.
-__global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
-    constexpr int C = 128, CIN = 512, HW = 32, BT = 16, HT = 18, HR = HT * HT, MH = 352, NGA = 41;
+// tiles, zeros stored for halo pixels outside the frame, so phase B needs no padding logic).  With NCT = C/32 channel
+// tiles of t1 / t2 the 8 waves form NCT x NG groups (NG = 8/NCT = 2 | 4):
+//   phase A  wave = (channel tile w % NCT, pixel tiles of group w / NCT: 6,5 | 3,3,3,2 of the 11)
+//   phase B  wave = (channel tile, 8/NG pixel tiles), shifted rows hb + ky*18 + kx of the halo image
+//   phase C  (4C/32)/8 chunks x (8 channel tiles = 8 waves) x 8 pixel tiles, store pass as in the frame kernel
+// LDS: [0, 125952) x ring (3 slots of 41 row groups) -> t1 (C/64 slices x 352 rows) -> t2 (C/64 x 256 rows); staging at 128 KB.
+template <int C>
+__global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
+    constexpr int CIN = 4 * C, HW = (C == 128) ? 32 : 64, BT = 16, HT = 18, HR = HT * HT, MH = 352, NGA = 41;
+    constexpr int TPX = HW / BT, TPF = TPX * TPX;    // tiles per frame edge / per frame
+    constexpr int NSL = C / 64, NCT = C / 32, NG = 8 / NCT;
+    constexpr int TPG = (11 + NG - 1) / NG;          // pixel tiles per group in phase A (6 | 3), the last group has one less
+    constexpr int HA0 = (TPG + 1) / 2, HA1 = TPG - HA0;   // rolling halves in phase A
+    constexpr int PB = 8 / NG, HB = PB / 2;          // pixel tiles per wave in phase B and per rolling half (4,2 | 2,1)
     constexpr int SLOT = NGA * 1024;                 // 41984 B per x K-tile
     constexpr int T1S = MH * ROWB, T2S = 256 * ROWB; // slice sizes of the t1 / t2 images
     constexpr int STG_OFF = 131072;
-    static_assert(3 * SLOT <= STG_OFF && 2 * T1S <= STG_OFF && 2 * SLOT + 8192 + MH * ROWB <= WIDE_LDS, "LDS map");
+    static_assert(3 * SLOT <= STG_OFF && NSL * T1S <= STG_OFF && 2 * SLOT + MH * ROWB <= WIDE_LDS && TPG * (NG - 1) + TPG - 1 == 11, "geometry");
     __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhalf = lane >> 5;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = L >> 2, tl = L & 3;
-    const int y0 = (tl >> 1) * BT, x0 = (tl & 1) * BT;
+    const int b = L / TPF, tl = L - b * TPF;
+    const int y0 = (tl / TPX) * BT, x0 = (tl % TPX) * BT;
     const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * HW * HW * CIN;
     bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * HW * HW * CIN;
     const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
-    const int ct4 = wave & 3, grp = wave >> 2;
+    const int ctw = wave % NCT, grp = wave / NCT;
 
-    // ================================================================ phase A: t1 = relu(Wa x + ba) on the halo, K = 512
+    // ================================================================ phase A: t1 = relu(Wa x + ba) on the halo, K = CIN
     {
         constexpr int NK = CIN / 64;
-        f32x16 acc[6];
+        f32x16 acc[TPG];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < TPG; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         const int rsub = lane >> 3, cpos = lane & 7;
@@ -410,10 +417,10 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
         auto load_w = [&](int kt, int set) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, ct4, CIN / 16, kt * 4 + ks, lane)) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, ctw, CIN / 16, kt * 4 + ks, lane)) : "memory");
         };
-        const int pt0 = grp * 6;                     // pixel tiles pt0 .. pt0 + npt - 1
-        const bool six = grp == 0;                   // group 0 has 6 tiles, group 1 has 5 (tile 10 is the last)
+        const int pt0 = grp * TPG;                   // pixel tiles pt0 .. ; the last group lacks its final tile (there are 11)
+        const bool full = grp + 1 < NG;
         load_w(0, 0);
         issue_x(0);
         issue_x(1);
@@ -427,28 +434,26 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
             if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
             if (kt + 2 < NK) issue_x(kt + 2);        // slot (kt+2) % 3 == slot of tile kt-1: done for every wave
             const unsigned xb = lds_base + (kt % 3) * SLOT;
-            u32x4 pf[6];
+            u32x4 pf[TPG];
             auto rd = [&](int ks, int half) {
                 const int ch = 2 * ks + lhalf;
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int t = half * 3 + i;
-                    if (t < 5 || six) pf[t] = lds_read_b128(xb + swz((pt0 + t) * 32 + lrow, ch));
-                }
+                for (int t = half ? HA0 : 0; t < (half ? TPG : HA0); ++t)
+                    if (t < TPG - 1 || full) pf[t] = lds_read_b128(xb + swz((pt0 + t) * 32 + lrow, ch));
             };
             rd(0, 0);
             rd(0, 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const u32x4 w = wq[par][ks];
-                if (six) lgkm_wait<3>(); else lgkm_wait<2>();
+                if (full) lgkm_wait<HA1>(); else lgkm_wait<HA1 - 1>();       // half 0 landed (half 1 may be in flight)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                for (int t = 0; t < HA0; ++t) acc[t] = mfma_bf16(w, pf[t], acc[t]);
                 if (ks < 3) rd(ks + 1, 0);
-                if (ks < 3) lgkm_wait<3>(); else lgkm_wait<0>();
-                acc[3] = mfma_bf16(w, pf[3], acc[3]);
-                acc[4] = mfma_bf16(w, pf[4], acc[4]);
-                if (six) acc[5] = mfma_bf16(w, pf[5], acc[5]);
+                if (ks < 3) lgkm_wait<HA0>(); else lgkm_wait<0>();
+#pragma unroll
+                for (int t = HA0; t < TPG; ++t)
+                    if (t < TPG - 1 || full) acc[t] = mfma_bf16(w, pf[t], acc[t]);
                 if (ks < 3) rd(ks + 1, 1);
             }
         }
@@ -456,10 +461,10 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
         asm volatile("" ::: "memory");
         float4 bq[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.ba + ct4 * 32 + 8 * g + 4 * lhalf);
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.ba + ctw * 32 + 8 * g + 4 * lhalf);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (i == 5 && !six) break;
+        for (int i = 0; i < TPG; ++i) {
+            if (i == TPG - 1 && !full) break;
             const int hr = (pt0 + i) * 32 + lrow;
             const int hy = hr / HT, hx = hr - hy * HT;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
                     u32x2 pk;
                     pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
                     pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
-                    lds_write_b64(lds_base + (ct4 >> 1) * T1S + hr * ROWB + ((((ct4 & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                    lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
             }
         }
@@ -479,57 +484,57 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
         asm volatile("" ::: "memory");
     }
 
-    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x 2 slices
+    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x NSL slices
     {
-        constexpr int KSB = 9 * C / 16;
-        f32x16 acc[4];
+        constexpr int KSB = 9 * C / 16, NSTEP = 9 * NSL;
+        f32x16 acc[PB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        int hb[4];                                   // halo row of this lane's output pixel at tap (0,0)
+        int hb[PB];                                  // halo row of this lane's output pixel at tap (0,0)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = (grp * 4 + i) * 32 + lrow;
+        for (int i = 0; i < PB; ++i) {
+            const int q = (grp * PB + i) * 32 + lrow;
             hb[i] = (q >> 4) * HT + (q & 15);
         }
         uint4 wn[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ct4, KSB, ks, lane);
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, ks, lane);
 #pragma unroll 1
-        for (int step = 0; step < 18; ++step) {      // step = tap * 2 + slice
-            const int tap = step >> 1, sl = step & 1;
+        for (int step = 0; step < NSTEP; ++step) {   // step = tap * NSL + slice
+            const int tap = step / NSL, sl = step - tap * NSL;
             u32x4 wc[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
-            if (step + 1 < 18) {
+            if (step + 1 < NSTEP) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ct4, KSB, (step + 1) * 4 + ks, lane);
+                for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
             }
-            unsigned rowa[4], rkey[4];
+            unsigned rowa[PB], rkey[PB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < PB; ++i) {
                 const int hr = hb[i] + (tap / 3) * HT + (tap % 3);
                 rowa[i] = lds_base + sl * T1S + hr * ROWB;
                 rkey[i] = (hr >> 1) & 7;
             }
-            u32x4 pf[4];
+            u32x4 pf[PB];
             auto rd = [&](int ks, int half) {
                 const int ch = 2 * ks + lhalf;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(rowa[half * 2 + i] + ((ch ^ rkey[half * 2 + i]) << 4));
+                for (int i = 0; i < HB; ++i) pf[half * HB + i] = lds_read_b128(rowa[half * HB + i] + ((ch ^ rkey[half * HB + i]) << 4));
             };
             rd(0, 0);
             rd(0, 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                lgkm_wait<2>();
-                acc[0] = mfma_bf16(wc[ks], pf[0], acc[0]);
-                acc[1] = mfma_bf16(wc[ks], pf[1], acc[1]);
+                lgkm_wait<HB>();
+#pragma unroll
+                for (int i = 0; i < HB; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
                 if (ks < 3) rd(ks + 1, 0);
-                if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
-                acc[2] = mfma_bf16(wc[ks], pf[2], acc[2]);
-                acc[3] = mfma_bf16(wc[ks], pf[3], acc[3]);
+                if (ks < 3) lgkm_wait<HB>(); else lgkm_wait<0>();
+#pragma unroll
+                for (int i = HB; i < PB; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
                 if (ks < 3) rd(ks + 1, 1);
             }
         }
@@ -537,16 +542,16 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
         asm volatile("" ::: "memory");
         float4 bq[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bb + ct4 * 32 + 8 * g + 4 * lhalf);
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bb + ctw * 32 + 8 * g + 4 * lhalf);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = (grp * 4 + i) * 32 + lrow;
+        for (int i = 0; i < PB; ++i) {
+            const int px = (grp * PB + i) * 32 + lrow;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 pk;
                 pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
                 pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
-                lds_write_b64(lds_base + (ct4 >> 1) * T2S + px * ROWB + ((((ct4 & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                lds_write_b64(lds_base + (ctw >> 1) * T2S + px * ROWB + ((((ctw & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
             }
         }
         lds_wait();
@@ -554,9 +559,9 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
         asm volatile("" ::: "memory");
     }
 
-    // ================================================================ phase C: y = relu(Wc t2 + bc + x), 2 chunks of 8 channel tiles
+    // ================================================================ phase C: y = relu(Wc t2 + bc + x), chunks of 8 channel tiles
     {
-        constexpr int KSC = C / 16;
+        constexpr int KSC = C / 16, NCH = (CIN / 32) / 8, NSTEP = NCH * NSL;
         f32x16 acc[8];
         float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
         const int u = lane & 3, prr = lane >> 2;
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, KSC, ks, lane);
 #pragma unroll 1
-        for (int chunk = 0; chunk < 2; ++chunk) {
+        for (int chunk = 0; chunk < NCH; ++chunk) {
             const int ct = chunk * 8 + wave;
             {
                 float4 bq[4];
@@ -579,14 +584,14 @@ __global__ __launch_bounds__(512) void bneck_halo128_kernel(BneckWideArgs p) {
                     }
             }
 #pragma unroll 1
-            for (int sl = 0; sl < 2; ++sl) {
+            for (int sl = 0; sl < NSL; ++sl) {
                 u32x4 wc[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
-                const int nxt = chunk * 2 + sl + 1;
-                if (nxt < 4) {
+                const int nxt = chunk * NSL + sl + 1;
+                if (nxt < NSTEP) {
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, (nxt >> 1) * 8 + wave, KSC, (nxt & 1) * 4 + ks, lane);
+                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, (nxt / NSL) * 8 + wave, KSC, (nxt % NSL) * 4 + ks, lane);
                 }
                 const unsigned tb = lds_base + sl * T2S;
                 u32x4 pf[8];
@@ -670,6 +675,7 @@ bool bneck_wide_fusable(const BneckWideArgs& a) {
     // 128-pixel workgroup and only B/2 workgroups make it slower (240 us) than the three layer kernels (201 us)
     if (a.Cmid == 512 && a.H == 8 && a.B % 2 == 0) return tune_get("FUSE_WIDE5", 0) != 0;
     if (a.Cmid == 128 && a.H == 32) return a.zeros != nullptr && tune_get("FUSE_WIDE3", 1) != 0;
+    if (a.Cmid == 64 && a.H == 64) return a.zeros != nullptr && tune_get("FUSE_WIDE2", 1) != 0;
     return a.Cmid == 256 && a.H == 16;
 }
 
@@ -677,7 +683,8 @@ void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st) {
     ConvArgs d{};
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
     void* tok = prof_begin(d, 2, st);
-    if (a.Cmid == 128) hipLaunchKernelGGL(bneck_halo128_kernel, dim3(a.B * 4), dim3(512), 0, st, a);
+    if (a.Cmid == 128) hipLaunchKernelGGL((bneck_halo_kernel<128>), dim3(a.B * 4), dim3(512), 0, st, a);
+    else if (a.Cmid == 64) hipLaunchKernelGGL((bneck_halo_kernel<64>), dim3(a.B * 16), dim3(512), 0, st, a);
     else if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 2>), dim3(a.B / 2), dim3(512), 0, st, a);
     prof_end(tok, st);

@@ -149,7 +149,7 @@ def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
     lib = L.lib()
     for B, edge in ((8, True), (3, False)):
         _, _, ttf, ttp = inputs(dev, B, edge)
-        for nm in ("res3", "res4", "res5"):
+        for nm in ("res2", "res3", "res4", "res5"):
             try:
                 lib.ivosw_tune_set(b"FUSE_WIDE", 1)
                 _, a = net16.forward_tap(ttf, ttp, nm)
@@ -174,7 +174,7 @@ def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
     lib = L.lib()
     _, _, ttf, ttp = inputs(dev, 8, True)      # B=8: res5 uses the 4-frame tile (B % 4 == 0)
     try:
-        for nm in ("res3", "res4", "res5"):
+        for nm in ("res2", "res3", "res4", "res5"):
             lib.ivosw_tune_set(b"PATCH3", 1)
             _, a = net16.forward_tap(ttf, ttp, nm)
             lib.ivosw_tune_set(b"PATCH3", 0)
