@@ -18,10 +18,12 @@ struct ConvPlan {
     int Cin, Cout, K, stride, pad;  // K = kernel size (1 or 3)
     int t_w, t_bn;                  // state_dict indices: conv weight; bn weight (bias, mean, var follow)
     size_t w_off, b_off;            // byte offsets into the packed arena
+    size_t fw_off;                  // bf16: 1x1 weights in MFMA-operand order for conv1x1_wide_kernel (0 = none)
 };
 
 struct BlockPlan {
     int c1, c2, c3, ds;  // indices into convs (ds = -1 if none)
+    size_t cat_fw_off;            // bf16: the concatenated weights in MFMA-operand order
     size_t cat_w_off, cat_b_off;  // first blocks: conv3 | downsample concatenated along K, bias sum (conv3 absorbs the downsample conv)
     size_t f1_off, f2_off, f3_off;  // bf16, identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
 };
@@ -57,6 +59,7 @@ static Plan make_plan(int dtype) {
         c.t_w = t; c.t_bn = t + 1; t += 6;
         c.w_off = take((size_t)cout * k * k * cin * es);
         c.b_off = take((size_t)cout * sizeof(float));
+        if (dtype == IVOSW_BF16 && k == 1 && cout % 256 == 0 && cin >= 384) c.fw_off = take((size_t)cout * cin * es);
         P.convs.push_back(c);
         return (int)P.convs.size() - 1;
     };
@@ -71,6 +74,7 @@ static Plan make_plan(int dtype) {
             if (b == 0) {
                 bp.cat_w_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
                 bp.cat_b_off = take((size_t)planes[s] * 4 * sizeof(float));
+                if (dtype == IVOSW_BF16 && planes[s] + inpl >= 384) bp.cat_fw_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
             } else if (dtype == IVOSW_BF16) {
                 bp.f1_off = take((size_t)planes[s] * inpl * es);
                 bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
@@ -162,6 +166,8 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
         launch_pack_conv(T(c.t_w), T(c.t_bn), T(c.t_bn + 1), T(c.t_bn + 2), T(c.t_bn + 3), c.Cout, c.Cin, c.K, c.K, dtype,
                          base + c.w_off, reinterpret_cast<float*>(base + c.b_off), st);
     }
+    for (const ConvPlan& c : P.convs)
+        if (c.fw_off) launch_fragpack(base + c.w_off, c.Cout, c.Cin, base + c.fw_off, st);
     for (const BlockPlan& bp : P.blocks)
         if (bp.f1_off) {
             const ConvPlan &c1 = P.convs[bp.c1], &c2 = P.convs[bp.c2], &c3 = P.convs[bp.c3];
@@ -175,6 +181,7 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
             launch_concat_k(base + c3.w_off, reinterpret_cast<const float*>(base + c3.b_off), c3.Cin, base + cd.w_off,
                             reinterpret_cast<const float*>(base + cd.b_off), cd.Cin, c3.Cout, dtype, base + bp.cat_w_off,
                             reinterpret_cast<float*>(base + bp.cat_b_off), st);
+            if (bp.cat_fw_off) launch_fragpack(base + bp.cat_w_off, c3.Cout, c3.Cin + cd.Cin, base + bp.cat_fw_off, st);
         }
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
@@ -241,7 +248,8 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 q.zeros = base + P.zero_off; q.x = in; q.w = base + c.w_off; q.bias = reinterpret_cast<const float*>(base + c.b_off); q.res = res; q.y = o;
                 q.B = nb; q.H = hin; q.W = hin; q.Cin = c.Cin; q.Ho = hout; q.Wo = hout; q.Cout = c.Cout;
                 q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
-                launch_conv(q, dtype, false, st);
+                if (dtype == IVOSW_BF16 && c.fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + c.fw_off, st);
+                else launch_conv(q, dtype, false, st);
             };
             if (dtype == IVOSW_BF16 && bp.f1_off && tune_get("FUSE_WIDE", 1)) {
                 BneckWideArgs q{};
@@ -286,7 +294,8 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 q.res = nullptr; q.y = y; q.B = nb; q.H = ho; q.W = ho; q.Cin = c3.Cin; q.Ho = ho; q.Wo = ho; q.Cout = c3.Cout;
                 q.KH = 1; q.KW = 1; q.stride = 1; q.pad = 0; q.relu = 1;
                 q.x2 = x; q.Cin2 = cd.Cin; q.H2 = hw; q.W2 = hw; q.stride2 = cd.stride;
-                launch_conv(q, dtype, false, st);
+                if (dtype == IVOSW_BF16 && bp.cat_fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + bp.cat_fw_off, st);
+                else launch_conv(q, dtype, false, st);
                 x = y;
                 hw = ho;
                 continue;

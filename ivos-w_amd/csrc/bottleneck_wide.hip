@@ -649,6 +649,182 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- 1x1 convolution in the same style (bf16, Cout % 256 == 0)
+// Phase A of the frame kernel as a layer of its own: a workgroup owns 256 output pixels x 256 output channels, the
+// pixel operand streams through a 4-slot LDS-DMA ring (32 KB per 64-channel K-tile), wave w streams the fragment-ordered
+// weights of channel tile 8*tile_n + w straight into registers, and the accumulators (initialised with the bias) leave
+// through the per-wave staging tile with the optional residual.  Against conv_igemm_ws_kernel (256 x 128 tile, weights
+// through LDS): half the LDS-DMA bytes per MFMA and no weight ring to synchronise on.  Serves the K-heavy 1x1 layers:
+// first-block reductions, conv3 + folded downsample (K-extension: second pixel source x2 sampled at stride2), res5.
+__global__ __launch_bounds__(512) void conv1x1_wide_kernel(ConvArgs p, const void* __restrict__ fw) {
+    constexpr int SLICE = 256 * ROWB, STG_OFF = 4 * SLICE;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int nbn = p.Cout / 256;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = L % nbn, tile_m = L / nbn;
+    const int m0 = tile_m * 256;
+    const int M = p.B * p.Ho * p.Wo;
+    const bf16_t* X = static_cast<const bf16_t*>(p.x);
+    const bf16_t* X2 = static_cast<const bf16_t*>(p.x2);
+    const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
+    const int K = p.Cin + (X2 ? p.Cin2 : 0);
+    const int NK = K / 64, NK1 = p.Cin / 64, KS = K / 16;
+    const int ct = tile_n * 8 + wave;
+
+    f32x16 acc[8];
+    {
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bias + ct * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias loads are out of the queue before the counted part starts
+    {
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const bf16_t* xs1[4];
+        const bf16_t* xs2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + rsub;
+            const int m = m0 + row;
+            const int chunk = (cpos ^ ((row >> 1) & 7)) * 8;
+            xs1[i] = xs2[i] = nullptr;
+            if (m < M) {
+                const int bb = m / (p.Ho * p.Wo);
+                const int rem = m - bb * (p.Ho * p.Wo);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                xs1[i] = X + (((size_t)bb * p.H + oy * p.stride) * p.W + ox * p.stride) * p.Cin + chunk;
+                if (X2) xs2[i] = X2 + (((size_t)bb * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.Cin2 + chunk;
+            }
+        }
+        auto issue_x = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* src = kt < NK1 ? (xs1[i] ? xs1[i] + kt * 64 : zeros) : (xs2[i] ? xs2[i] + (kt - NK1) * 64 : zeros);
+                dma16(src, lds + (kt & 3) * SLICE + (wave * 4 + i) * 1024);
+            }
+        };
+        u32x4 wq[2][4];
+        auto load_w = [&](int kt, int set) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(fw, ct, KS, kt * 4 + ks, lane)) : "memory");
+        };
+        u32x4 pf[8];
+        // queue per wave: W0 X0 X1 | iter kt: W(kt+1) X(kt+2) -> at the top of iter kt only X(kt+1) is younger than W(kt)
+        load_w(0, 0);
+        issue_x(0);
+        if (NK > 1) issue_x(1);
+        for (int kt2 = 0; kt2 < NK; kt2 += 2)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int kt = kt2 + par;
+            if (kt < NK) {
+                if (kt + 1 < NK) wait_vmcnt<4>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
+                if (kt + 2 < NK) issue_x(kt + 2);
+                const unsigned xb = lds_base + (kt & 3) * SLICE;
+                auto rd = [&](int ks, int half) {
+                    const int ch = 2 * ks + lhalf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(xb + swz((half * 4 + i) * 32 + lrow, ch));
+                };
+                rd(0, 0);
+                rd(0, 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 w = wq[par][ks];
+                    lgkm_wait<4>();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 0);
+                    if (ks < 3) lgkm_wait<4>(); else lgkm_wait<0>();
+#pragma unroll
+                    for (int i = 4; i < 8; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 1);
+                }
+            }
+        }
+    }
+    // store pass (the staging area is outside the ring: no barrier needed)
+    float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
+    const int u = lane & 3, prr = lane >> 2;
+    const bf16_t* R = static_cast<const bf16_t*>(p.res);
+    bf16_t* Y = static_cast<bf16_t*>(p.y);
+    const size_t cofs = (size_t)ct * 32 + 8 * u;
+    auto res_load = [&](int i, uint4 (&r)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int m = min(m0 + i * 32 + it * 16 + prr, M - 1);
+            r[it] = R ? *reinterpret_cast<const uint4*>(R + (size_t)m * p.Cout + cofs) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4 rr[2];
+    res_load(0, rr);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int slot = (2 * g + lhalf) ^ (lrow & 7);
+            *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        }
+        uint4 rn[2];
+        if (i < 7) res_load(i + 1, rn);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int pr = it * 16 + prr;
+            const int m = m0 + i * 32 + pr;
+            const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u) ^ (pr & 7)) << 2));
+            const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u + 1) ^ (pr & 7)) << 2));
+            const unsigned w4[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            unsigned pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float lo = v[2 * k] + __uint_as_float(w4[k] << 16), hi = v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u);
+                if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                pk[k] = pack2_bf16(lo, hi);
+            }
+            if (m < M) {
+                u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
+                if (p.nt & 1) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Y + (size_t)m * p.Cout + cofs));
+                else *reinterpret_cast<u32x4*>(Y + (size_t)m * p.Cout + cofs) = ov;
+            }
+        }
+        if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
+    }
+}
+
+bool conv1x1_wide_ok(const ConvArgs& a) {
+    // 256 x 256 tiles: res5's 2048 -> 512 reduction is half a workgroup per frame (128 workgroups at batch 256, half the
+    // chip empty) and stays on the 256 x 128 tiles of conv_igemm_ws_kernel.  The rule looks at the layer shape only,
+    // never at the batch: a frame's result must not depend on the chunk it was processed in.
+    const int wgs = a.Ho * a.Wo * (a.Cout / 256) >= 256 ? 192 : 0;
+    return a.KH == 1 && a.KW == 1 && a.pad == 0 && a.Cout % 256 == 0 && a.Cin % 64 == 0 && (!a.x2 || a.Cin2 % 64 == 0) &&
+           (a.Cin + (a.x2 ? a.Cin2 : 0)) >= tune_get("WIDE1X1_K", 384) && wgs >= tune_get("WIDE1X1_WGS", 192);
+}
+
+void launch_conv1x1_wide(const ConvArgs& a_in, const void* fw, hipStream_t st) {
+    ConvArgs a = a_in;
+    a.nt = tune_get("NT", 3);
+    void* tok = prof_begin(a, 2, st);
+    const int M = a.B * a.Ho * a.Wo;
+    const int grid = ((M + 255) / 256) * (a.Cout / 256);
+    hipLaunchKernelGGL(conv1x1_wide_kernel, dim3(grid), dim3(512), 0, st, a, fw);
+    prof_end(tok, st);
+}
+
 // [Cout][K] K-major packed bf16 weights -> MFMA-operand order [Cout/32][K/16][64 lanes][8]: lane l of fragment (ct, ks)
 // holds row ct*32 + (l & 31), k = ks*16 + 8*(l >> 5) .. +8
 __global__ void fragpack_kernel(const bf16_t* __restrict__ w, int Cout, int K, bf16_t* __restrict__ out) {

@@ -58,6 +58,9 @@ struct BneckWideArgs {
 bool bneck_wide_fusable(const BneckWideArgs& a);
 void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st);
 void launch_fragpack(const void* w, int Cout, int K, void* out, hipStream_t st);
+// bf16 1x1 convolution (optionally with the K-extension x2) on fragment-ordered weights `fw` (bottleneck_wide.hip)
+bool conv1x1_wide_ok(const ConvArgs& a);
+void launch_conv1x1_wide(const ConvArgs& a, const void* fw, hipStream_t st);
 
 // runtime tunables (capi.cpp): value of IVOSW_TUNE_<KEY> from the environment unless ivosw_tune_set() overrode it
 int tune_get(const char* key, int dflt);

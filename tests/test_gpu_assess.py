@@ -166,6 +166,32 @@ def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
             np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
 
 
+def test_wide_1x1_conv_matches_tiled_kernel(dev, net16):
+    """bf16 mode: the K-heavy 1x1 layers (first-block reductions, conv3 + folded downsample, res5) through
+    conv1x1_wide_kernel (fragment-ordered wave-private weights, tunable WIDE1X1=1, default) against the LDS-tiled
+    implicit-GEMM kernels: same operands and roundings, different fp32 accumulation order.  B=3 exercises the M tail
+    (192 res5 pixels in a 256-pixel tile)."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge in ((8, True), (3, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        for nm in ("res3", "res4", "res5"):
+            try:
+                lib.ivosw_tune_set(b"WIDE1X1", 1)
+                _, a = net16.forward_tap(ttf, ttp, nm)
+                sa = net16(ttf, ttp).cpu().numpy()
+                lib.ivosw_tune_set(b"WIDE1X1", 0)
+                _, b = net16.forward_tap(ttf, ttp, nm)
+                sb = net16(ttf, ttp).cpu().numpy()
+            finally:
+                lib.ivosw_tune_set(b"WIDE1X1", 1)
+            a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+            scale = np.abs(b).max()
+            assert np.abs(a - b).max() <= 2e-2 * scale, (nm, np.abs(a - b).max() / scale)
+            np.testing.assert_allclose(a.mean(), b.mean(), rtol=2e-3, err_msg=nm)
+            np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
+
+
 def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
     """bf16 mode: the 3x3 stride-1 layers with the halo patch LDS-resident (tunable PATCH3=1, default) against the
     per-tap implicit-GEMM kernel (PATCH3=0): same operands, same K order inside a tap, different accumulation order
