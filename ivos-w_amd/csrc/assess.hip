@@ -74,7 +74,11 @@ static Plan make_plan(int dtype) {
             if (b == 0) {
                 bp.cat_w_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
                 bp.cat_b_off = take((size_t)planes[s] * 4 * sizeof(float));
-                if (dtype == IVOSW_BF16 && planes[s] + inpl >= 384) bp.cat_fw_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
+                if (dtype == IVOSW_BF16 && (planes[s] + inpl >= 384 || s == 0)) bp.cat_fw_off = take((size_t)planes[s] * 4 * (planes[s] + inpl) * es);
+                if (dtype == IVOSW_BF16 && s == 0) {     // res2's first block (stride 1) is fused as a whole, too
+                    bp.f1_off = take((size_t)planes[s] * inpl * es);
+                    bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
+                }
             } else if (dtype == IVOSW_BF16) {
                 bp.f1_off = take((size_t)planes[s] * inpl * es);
                 bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
@@ -173,7 +177,7 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
             const ConvPlan &c1 = P.convs[bp.c1], &c2 = P.convs[bp.c2], &c3 = P.convs[bp.c3];
             launch_fragpack(base + c1.w_off, c1.Cout, c1.Cin, base + bp.f1_off, st);
             launch_fragpack(base + c2.w_off, c2.Cout, 9 * c2.Cin, base + bp.f2_off, st);
-            launch_fragpack(base + c3.w_off, c3.Cout, c3.Cin, base + bp.f3_off, st);
+            if (bp.f3_off) launch_fragpack(base + c3.w_off, c3.Cout, c3.Cin, base + bp.f3_off, st);
         }
     for (const BlockPlan& bp : P.blocks)
         if (bp.ds >= 0) {
@@ -257,6 +261,9 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 q.fa = base + bp.f1_off; q.ba = reinterpret_cast<const float*>(base + c1.b_off);
                 q.fb = base + bp.f2_off; q.bb = reinterpret_cast<const float*>(base + c2.b_off);
                 q.fc = base + bp.f3_off; q.bc = reinterpret_cast<const float*>(base + c3.b_off);
+                if (bp.ds >= 0) {
+                    q.ds = 1; q.fc = base + bp.cat_fw_off; q.bc = reinterpret_cast<const float*>(base + bp.cat_b_off);
+                }
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
                 if (bneck_wide_fusable(q)) {
                     launch_bneck_wide(q, st);

@@ -649,6 +649,335 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- res2, small tile: two workgroups per CU
+// The 16x16-tile kernel above runs ONE workgroup per CU, so its memory phases (x halo in, residual in / y out) and its
+// MFMA phases alternate instead of overlapping: 37k cycles per tile against ~10k of MFMA issue and ~18k of HBM time.
+// Here a workgroup owns an 8 x 16-pixel tile (10 x 18 halo = 180 rows, 6 pixel tiles), needs 72 KB of LDS and <= 128
+// VGPRs, and two of them share a CU: one is in the matrix cores while the other waits on memory.
+//   phase A  wave = (channel tile w & 1, pixel tiles g, g + 4 of the 6 with g = w >> 1); x through a 3-slot LDS-DMA ring
+//   phase B  wave = (channel tile w & 1, pixel-tile pair (w >> 1) & 1, K half w >> 2): 18 of the 36 k-steps each, so a
+//            Wb fragment serves two MFMAs; the upper K half hands its partial sums over through LDS (fp32)
+//   phase C  wave = output-channel tile w, 4 pixel tiles; store pass as above
+// LDS: [0, 73728) ring (3 x 24 KB) -> t1 [0, 23040) -> t2 [24576, 40960) ; [40960, 73728) partial sums, then staging.
+template <bool DS>
+__global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) {
+    constexpr int C = 64, CIN = DS ? 64 : 256, COUT = 256, NKA = CIN / 64, HW = 64, BTY = 8, BTX = 16, HTX = 18, HR = 180, NGA = 23;
+    constexpr int SLOT = 24576, T1_OFF = DS ? SLOT : 0, T2_OFF = SLOT, STG_OFF = DS ? 2 * SLOT : 40960;
+    // biases wait in LDS (a global load at the head of every epilogue would expose an L2 round trip each time): behind the
+    // staging area, or (DS: no room left under 80 KB) in the never-used tails of ring slot 0 and of the t1 image
+    constexpr int BAB_OFF = DS ? SLOT + 23040 : STG_OFF + 32768, BC_OFF = DS ? 23552 : BAB_OFF + 512;
+    constexpr int LDS_BYTES = STG_OFF + 32768 + (DS ? 0 : 1536);   // 75264 | 81920: two workgroups per CU either way
+    constexpr int TPXX = HW / BTX, TPF = (HW / BTY) * TPXX;   // 4 tiles across, 32 per frame
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = L / TPF, tl = L - b * TPF;
+    const int y0 = (tl / TPXX) * BTY, x0 = (tl % TPXX) * BTX;
+    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * HW * HW * CIN;
+    bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * HW * HW * COUT;
+    const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
+    const int ctw = wave & 1;
+    auto stamp = [&](int k) {
+        if (p.ts && tid == 0) p.ts[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    float bias_v = 0.f;                              // thread t: ba[t] | bb[t - 64] | bc[t - 128]
+    if (tid < 64) bias_v = p.ba[tid]; else if (tid < 128) bias_v = p.bb[tid - 64]; else if (tid < 384) bias_v = p.bc[tid - 128];
+    uint4 wnb[6], wnc[4], wd[4];                     // first weight fragments of phases B and C, requested one phase early
+    float4 bq[4];                                    // conv1 bias of this wave's channel tile (registers: used before the LDS copy is visible)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.ba + ctw * 32 + 8 * g + 4 * lhalf);
+
+    // ================================================================ phase A
+    {
+        const int grp = wave >> 1;
+        const bool two = grp < 2;                    // pixel tiles grp and grp + 4 (< 6)
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const int np = wave < 7 ? 3 : 2;             // row groups wave, wave + 8, wave + 16 (< 23)
+        const bf16_t* xsrc[3];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int g = wave + 8 * i;
+            const int hr = g * 8 + rsub;
+            const int hy = hr / HTX, hx = hr - hy * HTX;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NGA && hr < HR && y >= 0 && y < HW && x >= 0 && x < HW;
+            xsrc[i] = ok ? X + ((size_t)y * HW + x) * CIN + (cpos ^ ((hr >> 1) & 7)) * 8 : zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        auto issue_x = [&](int kt) {
+            unsigned char* sb = lds + (kt % 3) * SLOT;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int g = wave + 8 * i;
+                if (g < NGA) dma16(xsrc[i] + (((okmask >> i) & 1u) ? kt * 64 : 0), sb + g * 1024);
+            }
+        };
+        u32x4 wq[2][4];                              // Wa k-steps of K-tile kt in set kt & 1
+        auto load_w = [&](int kt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[kt & 1][ks]) : "v"(wfrag(p.fa, ctw, CIN / 16, kt * 4 + ks, lane)) : "memory");
+        };
+        load_w(0);
+        if (NKA > 1) load_w(1);
+        issue_x(0);
+        if (NKA > 1 && !(p.debug & 4)) { issue_x(1); issue_x(2); }
+#pragma unroll
+        for (int kt = 0; kt < NKA; ++kt) {
+            // in-order queue: W0 W1 X0 X1 X2 | W2 X3 (iteration 1) | W3 (iteration 2): younger than {W(kt), X(kt)} are
+            // X1 X2 | X2 | X3 | nothing
+            if ((p.debug & 4) || NKA == 1) wait_vmcnt<0>(); else
+            if (kt == 0) wait_vmcnt_n(2 * np); else if (kt < 3) wait_vmcnt_n(np); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt == 1 || kt == 2) load_w(kt + 1); // set (kt+1) & 1 held K-tile kt-1
+            if (kt == 1 && !(p.debug & 4)) issue_x(3);                 // slot 0: every wave is past K-tile 0
+            const unsigned xb = lds_base + (kt % 3) * SLOT;
+            u32x4 pf[2][2];
+            auto rd = [&](int ks, int buf) {
+                const int ch = 2 * ks + lhalf;
+                pf[buf][0] = lds_read_b128(xb + swz(grp * 32 + lrow, ch));
+                if (two) pf[buf][1] = lds_read_b128(xb + swz((grp + 4) * 32 + lrow, ch));
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) rd(ks + 1, (ks + 1) & 1);
+                if (ks < 3) { if (two) lgkm_wait<2>(); else lgkm_wait<1>(); } else lgkm_wait<0>();
+                if (p.debug & 16) continue;
+                acc[0] = mfma_bf16(wq[kt & 1][ks], pf[ks & 1][0], acc[0]);
+                if (two) acc[1] = mfma_bf16(wq[kt & 1][ks], pf[ks & 1][1], acc[1]);
+            }
+        }
+        stamp(1);
+        __builtin_amdgcn_s_barrier();                // the ring is dead: slot 0 becomes t1 (DS: x stays, t1 goes to slot 1)
+        asm volatile("" ::: "memory");
+        if (tid < 128) *reinterpret_cast<float*>(lds + BAB_OFF + tid * 4) = bias_v;
+        else if (tid < 384) *reinterpret_cast<float*>(lds + BC_OFF + (tid - 128) * 4) = bias_v;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wnb[j] = *wfrag(p.fb, ctw, 36, (wave >> 2) * 18 + j, lane);
+
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && !two) break;
+            const int hr = (grp + 4 * i) * 32 + lrow;
+            const int hy = hr / HTX, hx = hr - hy * HTX;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool in = y >= 0 && y < HW && x >= 0 && x < HW;
+            if (hr < HR) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk;
+                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
+                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    lds_write_b64(lds_base + T1_OFF + hr * ROWB + (((ctw * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                }
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(2);
+    }
+
+    // ================================================================ phase B: 36 k-steps (tap * 4 + ks), split over wave >> 2
+    {
+        const int pp = (wave >> 1) & 1, kh = wave >> 2;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int hb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = (pp * 2 + i) * 32 + lrow;
+            hb[i] = (q >> 4) * HTX + (q & 15);
+        }
+        const int k0 = kh * 18;
+#pragma unroll
+        for (int c6 = 0; c6 < 3; ++c6) {
+            if (p.debug & 8) break;
+            u32x4 wc[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) wc[j] = as_u32x4(wnb[j]);
+            if (c6 < 2) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) wnb[j] = *wfrag(p.fb, ctw, 36, k0 + (c6 + 1) * 6 + j, lane);
+            }
+            u32x4 pf[2][2];
+            auto rd = [&](int j, int buf) {
+                const int kstep = k0 + c6 * 6 + j;
+                const int tap = kstep >> 2, ch = 2 * (kstep & 3) + lhalf;
+                const int toff = (tap / 3) * HTX + (tap % 3);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int hr = hb[i] + toff;
+                    pf[buf][i] = lds_read_b128(lds_base + T1_OFF + hr * ROWB + ((ch ^ ((hr >> 1) & 7)) << 4));
+                }
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (j < 5) rd(j + 1, (j + 1) & 1);
+                if (j < 5) lgkm_wait<2>(); else lgkm_wait<0>();
+                acc[0] = mfma_bf16(wc[j], pf[j & 1][0], acc[0]);
+                acc[1] = mfma_bf16(wc[j], pf[j & 1][1], acc[1]);
+            }
+        }
+        stamp(3);
+        constexpr int KSC = DS ? 8 : 4;              // DS: [conv3 | downsample] concatenated along K, second half reads x
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wnc[ks] = *wfrag(p.fc, wave, KSC, ks, lane);
+        if (DS) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wd[ks] = *wfrag(p.fc, wave, KSC, 4 + ks, lane);
+        }
+        // upper K half -> partial sums to LDS; lower K half adds them, + bias, ReLU -> t2
+        float* scr = reinterpret_cast<float*>(lds + STG_OFF + (wave & 3) * 8192);
+        if (kh) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(scr + ((i * 4 + g) * 64 + lane) * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+        }
+        __syncthreads();
+        if (!kh) {
+            float4 bq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BAB_OFF + 256 + (ctw * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int px = (pp * 2 + i) * 32 + lrow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 o = *reinterpret_cast<const float4*>(scr + ((i * 4 + g) * 64 + lane) * 4);
+                    u32x2 pk;
+                    pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + o.x + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + o.y + bq[g].y, 0.f));
+                    pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + o.z + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + o.w + bq[g].w, 0.f));
+                    lds_write_b64(lds_base + T2_OFF + px * ROWB + (((ctw * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                }
+            }
+        }
+        __syncthreads();
+        stamp(4);
+    }
+
+    // ================================================================ phase C: wave = output-channel tile
+    {
+        f32x16 acc[4];
+        float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
+        const int u = lane & 3, prr = lane >> 2;
+        auto pix = [&](int q) { return (size_t)((y0 + (q >> 4)) * HW + x0 + (q & 15)) * COUT; };
+
+        const size_t cofs = (size_t)wave * 32 + 8 * u;
+        uint4 rr[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) rr[it] = (DS || (p.debug & 2)) ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
+        {
+            float4 bq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BC_OFF + (wave * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+                }
+        }
+        const unsigned tb = lds_base + T2_OFF;
+        u32x4 pf[4];
+        auto rd = [&](int ks, int half) {
+            const int ch = 2 * ks + lhalf;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(tb + swz((half * 2 + i) * 32 + lrow, ch));
+        };
+        rd(0, 0);
+        rd(0, 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const u32x4 w = as_u32x4(wnc[ks]);
+            lgkm_wait<2>();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+            if (ks < 3) rd(ks + 1, 0);
+            if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
+#pragma unroll
+            for (int i = 2; i < 4; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+            if (ks < 3) rd(ks + 1, 1);
+        }
+        if (DS) {                                    // + Wd x on the tile's centre pixels, still in ring slot 0
+            unsigned xrow[4], xkey[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = i * 32 + lrow;
+                const int hr = ((q >> 4) + 1) * HTX + (q & 15) + 1;
+                xrow[i] = lds_base + hr * ROWB;
+                xkey[i] = (hr >> 1) & 7;
+            }
+            auto rdx = [&](int ks, int half) {
+                const int ch = 2 * ks + lhalf;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(xrow[half * 2 + i] + ((ch ^ xkey[half * 2 + i]) << 4));
+            };
+            rdx(0, 0);
+            rdx(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 w = as_u32x4(wd[ks]);
+                lgkm_wait<2>();
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                if (ks < 3) rdx(ks + 1, 0);
+                if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
+#pragma unroll
+                for (int i = 2; i < 4; ++i) acc[i] = mfma_bf16(w, pf[i], acc[i]);
+                if (ks < 3) rdx(ks + 1, 1);
+            }
+        }
+        stamp(5);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int slot = (2 * g + lhalf) ^ (lrow & 7);
+                *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+            }
+            uint4 rn[2];
+            if (i < 3) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) rn[it] = (DS || (p.debug & 2)) ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix((i + 1) * 32 + it * 16 + prr) + cofs);
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int pr = it * 16 + prr;
+                const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u) ^ (pr & 7)) << 2));
+                const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u + 1) ^ (pr & 7)) << 2));
+                const unsigned w4[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                unsigned pk[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                if (!(p.debug & 1) || pk[0] == 0x12345678u) *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+            if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
+        }
+        stamp(6);
+    }
+}
+
 // ---------------------------------------------------------------- 1x1 convolution in the same style (bf16, Cout % 256 == 0)
 // Phase A of the frame kernel as a layer of its own: a workgroup owns 256 output pixels x 256 output channels, the
 // pixel operand streams through a 4-slot LDS-DMA ring (32 KB per 64-channel K-tile), wave w streams the fragment-ordered
@@ -846,6 +1175,8 @@ void launch_fragpack(const void* w, int Cout, int K, void* out, hipStream_t st) 
 }
 
 bool bneck_wide_fusable(const BneckWideArgs& a) {
+    // first block of res2 (stride 1): fc = [conv3 | downsample] along K, bc = bias sum, no residual
+    if (a.ds) return a.fa && a.fb && a.fc && a.zeros && a.Cmid == 64 && a.Cin == 64 && a.H == 64 && a.W == 64 && tune_get("HALO64S_DS", 1) != 0;
     if (!a.fa || !a.fb || !a.fc || a.Cin != 4 * a.Cmid || a.H != a.W) return false;
     // res5 (Cmid 512, 8x8 frames, two per workgroup) is instantiated and correct but NOT used: 8.7 MB of weights per
     // 128-pixel workgroup and only B/2 workgroups make it slower (240 us) than the three layer kernels (201 us)
@@ -855,11 +1186,15 @@ bool bneck_wide_fusable(const BneckWideArgs& a) {
     return a.Cmid == 256 && a.H == 16;
 }
 
-void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st) {
+void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
+    BneckWideArgs a = a_in;
+    a.debug = tune_get("BDBG", 0);
     ConvArgs d{};
-    d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
+    d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.ds ? nullptr : a.x;
     void* tok = prof_begin(d, 2, st);
     if (a.Cmid == 128) hipLaunchKernelGGL((bneck_halo_kernel<128>), dim3(a.B * 4), dim3(512), 0, st, a);
+    else if (a.ds) hipLaunchKernelGGL(bneck_halo64s_kernel<true>, dim3(a.B * 32), dim3(512), 0, st, a);
+    else if (a.Cmid == 64 && tune_get("HALO64S", 1)) hipLaunchKernelGGL(bneck_halo64s_kernel<false>, dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64) hipLaunchKernelGGL((bneck_halo_kernel<64>), dim3(a.B * 16), dim3(512), 0, st, a);
     else if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 2>), dim3(a.B / 2), dim3(512), 0, st, a);
@@ -869,7 +1204,8 @@ void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st) {
 }  // namespace ivosw
 
 // Tuning probe: one wide fused bottleneck launch (weights given K-major packed; fragment-ordered copies are made into
-// `frag`, >= 2 * (Cmid*Cin + 9*Cmid*Cmid + Cin*Cmid) bytes) with phase stamps ts [B][8] (may be NULL).
+// `frag`, >= 2 * (Cmid*Cin + 9*Cmid*Cmid + Cin*Cmid) + 256 bytes, the last 256 zero) with phase stamps ts [workgroups][8]
+// (may be NULL).
 extern "C" int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, const float* ba, const void* wb, const float* bb,
                                       const void* wc, const float* bc, void* frag, int B, int H, int W, int Cin, int Cmid,
                                       unsigned long long* ts, ivosw_stream_t stream) {
@@ -884,6 +1220,7 @@ extern "C" int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, co
     BneckWideArgs a{};
     a.x = x; a.y = y; a.fa = f; a.ba = ba; a.fb = f + n1; a.bb = bb; a.fc = f + n1 + n2; a.bc = bc;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cmid = Cmid; a.ts = ts;
+    a.zeros = f + 2 * n1 + n2;                      // the caller provides 256 zeroed bytes behind the three weight copies
     IVOSW_REQUIRE(bneck_wide_fusable(a), "shape is not covered by the wide fused bottleneck kernel");
     launch_bneck_wide(a, st);
     IVOSW_CHECK_LAUNCH();

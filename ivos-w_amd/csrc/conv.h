@@ -54,6 +54,9 @@ struct BneckWideArgs {
     const void* zeros;                 // >= 256 B of device zeros (halo variant)
     int B, H, W, Cin, Cmid;
     unsigned long long* ts;            // optional [B][8] s_memtime stamps at the phase boundaries (ivosw_bneck_wide_probe)
+    int ds;                            // 1: first block of res2 (Cin = Cmid = 64): fc = [conv3 | downsample] along K (K = 128), bc = bias sum
+    int debug;                         // ablation bits (tunable BDBG; timing experiments only): 1 no y stores, 2 no residual
+                                       // loads, 4 x DMA for the first K-tile only, 8 skip phase B, 16 skip phase A MFMAs
 };
 bool bneck_wide_fusable(const BneckWideArgs& a);
 void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st);

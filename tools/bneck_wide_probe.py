@@ -9,7 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ivos_w_amd import _lib as L  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-H, Cin, Cm = 16, 1024, 256
+Cm = int(sys.argv[2]) if len(sys.argv) > 2 else 256      # 256: res4 frame kernel, 128 / 64: halo kernels of res3 / res2
+H, Cin = {256: 16, 128: 32, 64: 64}[Cm], 4 * Cm
+NWG = B * {256: 1, 128: 4, 64: 32}[Cm]
 dev = torch.device("cuda:0")
 lib = L.lib()
 g = torch.Generator(device=dev).manual_seed(0)
@@ -19,8 +21,8 @@ wa = (torch.randn(Cm, Cin, device=dev, generator=g) / Cin ** 0.5).to(torch.bfloa
 wb = (torch.randn(Cm, 9 * Cm, device=dev, generator=g) / (9 * Cm) ** 0.5).to(torch.bfloat16)
 wc = (torch.randn(Cin, Cm, device=dev, generator=g) / Cm ** 0.5).to(torch.bfloat16)
 ba, bb, bc = (torch.randn(n, device=dev, generator=g) * 0.1 for n in (Cm, Cm, Cin))
-frag = torch.empty(2 * (Cm * Cin * 2 + 9 * Cm * Cm), device=dev, dtype=torch.uint8)
-ts = torch.zeros(B, 8, device=dev, dtype=torch.int64)
+frag = torch.zeros(2 * (Cm * Cin * 2 + 9 * Cm * Cm) + 256, device=dev, dtype=torch.uint8)
+ts = torch.zeros(NWG, 8, device=dev, dtype=torch.int64)
 st = L.stream_ptr(dev)
 
 
@@ -47,7 +49,7 @@ d = np.diff(t[:, :7], axis=1)
 names = ["A k-loop", "t1 store", "B taps", "t2 store", "C chunks 0-2 + mfma 3", "C last store pass"]
 for i, n in enumerate(names):
     print(f"{n:24s} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 10):8.0f} {np.percentile(d[:, i], 90):8.0f}")
-print(f"{'total':24s} {(t[:, 6] - t[:, 0]).mean():9.0f}")
+print(f"{'total':24s} {(t[:, 6] - t[:, 0]).mean():9.0f}   (shader clocks per workgroup)")
 xf = x[:2].float().permute(0, 3, 1, 2)
 t1 = torch.relu(torch.nn.functional.conv2d(xf, wa.float()[:, :, None, None], ba)).to(torch.bfloat16).float()
 wb4 = wb.float().view(Cm, 3, 3, Cm).permute(0, 3, 1, 2)
