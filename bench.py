@@ -13,7 +13,7 @@ The same JSON line also carries, as `dqn`, the second half of BASELINE's metric:
 3 forwards + loss + BPTT -> [RCCL all-reduce of the 724 KB gradient arena when N>1] -> clamp+Adam ->
 target-sync coin flip).  `--workload dqn` makes that the headline `value` instead.
 
-roofline: dominant kernel family = the tower's contraction kernels, conv_igemm* (layer by layer) and bneck64* (whole
+roofline: dominant kernel family = the tower's contraction kernels, conv_igemm* | conv1x1_wide* | conv3x3_patch* (layer by layer), stem_pool* and bneck* (whole
 res2 bottlenecks fused) (bound: bf16 MFMA, 2.5 PFLOP/s dense).  achieved = algorithmic conv FLOPs per launch /
 average launch duration, timed with HIP events on the launch stream inside the library
 (ivosw_profile_start/stop) over extra steps that run right after the timed region, so the events do not perturb

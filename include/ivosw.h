@@ -119,7 +119,7 @@ const char* ivosw_assess_dominant_kernel(int dtype);
 
 /* ------------------------------------------------------------------ measurement hooks ---------- */
 /* Not part of the reference surface: bench.py's roofline leg.  Between start and stop every launch of
- * the dominant kernel family (conv_igemm*, bneck64*) is bracketed by hipEvents on the launch stream; stop
+ * the dominant kernel family (conv_igemm*, conv1x1_wide*, conv3x3_patch*, bneck*, stem_pool*) is bracketed by hipEvents on the launch stream; stop
  * synchronises those events and returns the summed kernel time (ms) and the launch count.          */
 int ivosw_profile_start(void);
 int ivosw_profile_stop(double* total_ms, int* launches);

@@ -200,7 +200,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
-    return dtype == IVOSW_BF16 ? "conv_igemm*|conv3x3_patch*|bneck64*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
+    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
 extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp, int B, int H, int W,

@@ -38,11 +38,14 @@ def test_host_only_queries(handle):
     assert lib.ivosw_version() >= 100
     assert lib.ivosw_brain_ws_bytes(128, 25) > 0 and lib.ivosw_brain_ws_bytes(0, 25) == 0
     assert lib.ivosw_dqn_ws_bytes(128, 25) > lib.ivosw_brain_ws_bytes(128, 25)
-    assert lib.ivosw_assess_packed_bytes(L.BF16) < lib.ivosw_assess_packed_bytes(L.F32)
+    # 23.5 M parameters: fp32 arena ~ 4 B each (+ folded downsample copies); the bf16 arena holds the K-major weights AND
+    # their MFMA-fragment-ordered copies for the fused / wide kernels, so it is 2-3 x 47 MB
+    nb16, nb32 = lib.ivosw_assess_packed_bytes(L.BF16), lib.ivosw_assess_packed_bytes(L.F32)
+    assert 94e6 < nb32 < 130e6 and 47e6 < nb16 < 150e6
     assert lib.ivosw_assess_packed_bytes(7) == 0
     assert lib.ivosw_assess_ws_bytes(L.BF16, 256, 480, 854, 0) > 0
     fam = lib.ivosw_assess_dominant_kernel(L.BF16).decode().split("|")
-    assert "conv_igemm*" in fam and "bneck64*" in fam           # kernel-name patterns of the tower's contraction kernels
+    assert "conv_igemm*" in fam and "bneck*" in fam           # kernel-name patterns of the tower's contraction kernels
     assert lib.ivosw_assess_dominant_kernel(L.F32).decode() == "conv_igemm*"
     assert lib.ivosw_tune_set(b"FUSE", 1) == 0 and lib.ivosw_tune_set(None, 1) != 0
 
