@@ -180,6 +180,41 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     return world * steps / dt, dt
 
 
+def bench_jf(rank, world, dev, dist, steps=20, warmup=3, N=100, O=3):
+    """DAVIS J and F of one 100-frame 480p sequence with 3 objects per step, label maps resident in
+    HBM as uint8, counts left on the device (the host ratio step is a few hundred float64 divisions).  HBM-bound:
+    algorithmic bytes = 2 label maps read once."""
+    from ivos_w_amd import metrics
+    gt, pr = synth.label_maps(N, 480, 854, O, seed=4 + rank)
+    tg, tp = torch.from_numpy(gt).to(dev), torch.from_numpy(pr).to(dev)
+    lib = L.lib()
+    counts = torch.empty((N, O, 6), dtype=torch.int64, device=dev)
+    nbytes = lib.ivosw_jf_ws_bytes(N, 480, 854, O)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ids = bytes(range(1, O + 1))
+    st = L.stream_ptr(dev)
+
+    def step():
+        L.check(lib.ivosw_jf_counts(L.dptr(tg), L.dptr(tp), N, 480, 854, ids, O, 8, L.dptr(counts), L.dptr(ws), nbytes, st), "jf")
+    dt = timed(step, steps, warmup, dev, dist)
+    fps = world * N * steps / dt
+    out = {"metric": "jf_scored_frames_per_sec", "value": round(fps, 1), "unit": "frames/s (480p, 3 objects, J and F)",
+           "us_per_sequence": round(dt / steps * 1e6, 1), "dtype": "u8",
+           "roofline": {"bound": "hbm", "achieved": round(2 * N * 480 * 854 * steps / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(2 * N * 480 * 854 * steps / dt / 8e12, 4),
+                        "note": "algorithmic bytes = both label maps read once (820 KB per frame); the boundary-match pass works on bit maps 8x smaller"}}
+    if rank == 0 and world == 1:
+        from oracle import jf_oracle as jo          # checker + CPU baseline only
+        j, f = metrics.batched_j_and_f(tg[:4], tp[:4], nb_objects=O)
+        assert np.array_equal(j, jo.batched_jaccard(gt[:4], pr[:4], nb_objects=O)) and np.array_equal(f, jo.batched_f_measure(gt[:4], pr[:4], nb_objects=O))
+        t0 = time.perf_counter()
+        jo.sequence_metric("J_AND_F", gt[:8], pr[:8], O)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(8 / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "8 frames x 3 objects, numpy/scipy oracle of davisinteractive's batched_jaccard + batched_f_measure"}
+    return out
+
+
 def cpu_baseline_assess():
     from oracle import assess_oracle as ao
     sd = ao.to_torch_sd(synth.assessnet_state_dict(0))
@@ -258,6 +293,10 @@ def main():
                      "roofline": {"bound": "mfma", "achieved": round(10.5e9 * sps / world / 1e12, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(10.5e9 * sps / world / 1e12 / PEAK_F32_TFLOPS, 5), "traffic": None,
                                   "note": "whole-step algorithmic 10.5 GFLOP / step time: the step is latency-bound (SURVEY §8d)"}})
+    if args.workload == "assess":
+        line["jf"] = bench_jf(rank, world, dev, dist)
+        if args.no_cpu_baseline:
+            line["jf"].pop("cpu_baseline", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_assess() if args.workload == "assess" else cpu_baseline_dqn()
         if args.workload == "assess":

@@ -117,6 +117,19 @@ int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const f
 /* Kernel-name patterns of the dominant kernel family (the tower's contraction kernels) for profiling. */
 const char* ivosw_assess_dominant_kernel(int dtype);
 
+/* ------------------------------------------------------------------ J / F metrics - */
+/* Replaces davisinteractive.metrics.batched_jaccard / batched_f_measure as utils/misc.py:136-160
+ * (sequence_metric) calls them.  gt, pred: device uint8 label maps [N,H,W]; obj_ids: HOST array of the
+ * n_obj (<= 32) label values to score; bound_pix = the F-measure tolerance in pixels, as the reference
+ * derives it (bound_th if >= 1 else ceil(bound_th * |(H,W)|_2), bound_th = 0.008; <= 32).  Writes the six
+ * INTEGER counts per (frame, object) to the device array counts [N][n_obj][6] =
+ *   { |gt & pred|, |gt | pred|, #pred-boundary, #gt-boundary, #pred-boundary within dil(gt-boundary),
+ *     #gt-boundary within dil(pred-boundary) };
+ * the host forms J and F from them with the reference's float64 expressions (ivos_w_amd/metrics.py).    */
+size_t ivosw_jf_ws_bytes(int N, int H, int W, int n_obj);
+int ivosw_jf_counts(const uint8_t* gt, const uint8_t* pred, int N, int H, int W, const uint8_t* obj_ids,
+                    int n_obj, int bound_pix, int64_t* counts, void* ws, size_t ws_bytes, ivosw_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks ---------- */
 /* Not part of the reference surface: bench.py's roofline leg.  Between start and stop every launch of
  * the dominant kernel family (conv_igemm*, conv1x1_wide*, conv3x3_patch*, bneck*, stem_pool*) is bracketed by hipEvents on the launch stream; stop

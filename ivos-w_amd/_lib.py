@@ -35,6 +35,8 @@ SIGNATURES = {
     "ivosw_assess_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ivosw_assess_forward": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _sz, _i, _i, _p, _p]),
     "ivosw_assess_dominant_kernel": (C.c_char_p, [_i]),
+    "ivosw_jf_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "ivosw_jf_counts": (_i, [_p, _p, _i, _i, _i, C.c_char_p, _i, _i, _p, _p, _sz, _p]),
     "ivosw_profile_start": (_i, []),
     "ivosw_profile_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "ivosw_profile_report": (_i, [C.c_char_p, _sz]),

@@ -212,3 +212,28 @@ def collate_np(tr, idx):
     for k in ("old_state_iou", "new_state_iou", "annotated_frames", "next_annotated_frames"):
         out[k] = tr[k][idx][:, None, :]
     return out
+
+
+def label_maps(N, H=480, W=854, n_obj=3, seed=11, void=False):
+    """Synthetic multi-object segmentation pair for the J/F metrics: `gt` = n_obj drifting ellipses (label o+1, later
+    objects on top), `pred` = the same ellipses with per-frame jitter of centre / radii, so that IoU and boundary
+    matches vary from frame to frame; frame 0 of `pred` is an exact copy, the last frame lacks the last object.
+    Returns (gt, pred) uint8 [N,H,W]; `void` sprinkles a 255 (ignore) region into gt."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    gt = np.zeros((N, H, W), np.uint8)
+    pred = np.zeros((N, H, W), np.uint8)
+    cy, cx = rs.uniform(0.25, 0.75, n_obj) * H, rs.uniform(0.25, 0.75, n_obj) * W
+    ry, rx = rs.uniform(0.05, 0.22, n_obj) * H, rs.uniform(0.05, 0.22, n_obj) * W
+    for n in range(N):
+        for o in range(n_obj):
+            y0, x0 = cy[o] + 0.01 * H * n * (-1) ** o, cx[o] + 0.012 * W * n
+            gt[n][((yy - y0) / ry[o]) ** 2 + ((xx - x0) / rx[o]) ** 2 <= 1.0] = o + 1
+            if n == N - 1 and o == n_obj - 1 and N > 1:
+                continue
+            jy, jx = (0.0, 0.0) if n == 0 else rs.uniform(-0.02, 0.02, 2) * (H, W)
+            sy, sx = (1.0, 1.0) if n == 0 else rs.uniform(0.9, 1.1, 2)
+            pred[n][((yy - y0 - jy) / (ry[o] * sy)) ** 2 + ((xx - x0 - jx) / (rx[o] * sx)) ** 2 <= 1.0] = o + 1
+    if void:
+        gt[:, : max(1, H // 20), : max(1, W // 10)] = 255
+    return gt, pred

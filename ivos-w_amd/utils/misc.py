@@ -95,10 +95,28 @@ def load_agent_checkpoint(agent, ckpt_dir, device="cpu", strict=False):
         return -1
 
 
-def sequence_metric(*args, **kwargs):
-    try:
-        from davisinteractive.metrics.jaccard import batched_f_measure, batched_jaccard  # noqa: F401
-    except ImportError as e:
-        raise ImportError("sequence_metric needs the third-party `davisinteractive` package (J&F metrics); it is "
-                          "outside the MI355X hot path and not vendored") from e
-    raise NotImplementedError("J&F via davisinteractive is outside the hot path scope of this build")
+def sequence_metric(metric_to_optimize, gt_masks, pred_masks, nb_objects, average_over_objects=True,
+                    convert_to_single_obj=False):
+    """utils/misc.py:118-162 with the davisinteractive metrics computed on the device (ivos_w_amd.metrics).
+
+    gt_masks / pred_masks: [N,H,W] integer label maps, numpy arrays (as the reference's callers pass them) or tensors
+    (device tensors avoid the upload).  Returns the numpy float64 array the reference returns.  Like the reference,
+    ``convert_to_single_obj`` rewrites the caller's arrays in place."""
+    from .. import metrics
+
+    if convert_to_single_obj:
+        gt_masks[gt_masks > 0] = 1
+        pred_masks[pred_masks > 0] = 1
+        nb_objects = 1
+
+    if metric_to_optimize == 'J':
+        metric = metrics.batched_jaccard(gt_masks, pred_masks, average_over_objects=average_over_objects,
+                                         nb_objects=nb_objects)
+    elif metric_to_optimize == 'F':
+        metric = metrics.batched_f_measure(gt_masks, pred_masks, average_over_objects=average_over_objects,
+                                           nb_objects=nb_objects)
+    elif metric_to_optimize == 'J_AND_F':
+        jaccard, contour = metrics.batched_j_and_f(gt_masks, pred_masks, average_over_objects=average_over_objects,
+                                                   nb_objects=nb_objects)
+        metric = .5 * jaccard + .5 * contour
+    return metric
