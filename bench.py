@@ -215,6 +215,36 @@ def bench_jf(rank, world, dev, dist, steps=20, warmup=3, N=100, O=3):
     return out
 
 
+def bench_seg(rank, world, dev, dist, steps=20, warmup=3, n=100, C=4):
+    """upsample + argmax + softmax epilogue for one 100-frame sequence per step (stride-4 logits of
+    3 objects + background -> 480p), probabilities written once, object-major.  HBM-bound on the outputs."""
+    from ivos_w_amd.utils import utils_manet
+    g = torch.Generator(device=dev).manual_seed(5 + rank)
+    x = torch.randn(n, C, 120, 214, device=dev, generator=g) * 3
+    store = utils_manet.ProbStore(n, C, 480, 854, dev)
+
+    def step():
+        utils_manet.seg_epilogue(x, 480, 854, store, 0)
+    dt = timed(step, steps, warmup, dev, dist)
+    out_bytes = n * 480 * 854 * (C * 4 + 8 + 1 + 4)       # probs + int64 / uint8 / float labels
+    res = {"metric": "seg_epilogue_frames_per_sec", "value": round(world * n * steps / dt, 1), "unit": "frames/s (480p, 4 channels)",
+           "us_per_sequence": round(dt / steps * 1e6, 1), "dtype": "f32",
+           "roofline": {"bound": "hbm", "achieved": round(out_bytes * steps / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(out_bytes * steps / dt / 8e12, 4),
+                        "note": "algorithmic bytes = outputs written once (29 B per pixel); the stride-4 logits are 1/16 of a channel plane"}}
+    if rank == 0 and world == 1:
+        from oracle import seg_oracle as so           # checker + CPU baseline only
+        xc = x[:4].cpu()
+        t0 = time.perf_counter()
+        up, lab = so.epilogue(xc, 480, 854)
+        pc = torch.softmax(up, 1)
+        cdt = time.perf_counter() - t0
+        assert (store.all_P[:4].cpu() - pc).abs().max().item() < 2e-6
+        res["cpu_baseline"] = {"value": round(4 / cdt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "4 frames, torch-CPU interpolate + argmax + softmax (the reference's own calls)"}
+    return res
+
+
 def cpu_baseline_assess():
     from oracle import assess_oracle as ao
     sd = ao.to_torch_sd(synth.assessnet_state_dict(0))
@@ -295,8 +325,10 @@ def main():
                                   "note": "whole-step algorithmic 10.5 GFLOP / step time: the step is latency-bound (SURVEY §8d)"}})
     if args.workload == "assess":
         line["jf"] = bench_jf(rank, world, dev, dist)
+        line["seg_epilogue"] = bench_seg(rank, world, dev, dist)
         if args.no_cpu_baseline:
             line["jf"].pop("cpu_baseline", None)
+            line["seg_epilogue"].pop("cpu_baseline", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_assess() if args.workload == "assess" else cpu_baseline_dqn()
         if args.workload == "assess":

@@ -130,6 +130,17 @@ size_t ivosw_jf_ws_bytes(int N, int H, int W, int n_obj);
 int ivosw_jf_counts(const uint8_t* gt, const uint8_t* pred, int N, int H, int W, const uint8_t* obj_ids,
                     int n_obj, int bound_pix, int64_t* counts, void* ws, size_t ws_bytes, ivosw_stream_t stream);
 
+/* ------------------------------------------------------------------ segmentation epilogue (8f-4) */
+/* Replaces, per frame batch, F.interpolate(logits, (H,W), 'bilinear', align_corners=True) -> argmax(dim=1)
+ * [-> .float()] and the final torch.softmax(cat(probs), 1) of utils/utils_manet.py:78-84,110-116,146-151,
+ * 160-161.  logits: device [n,C,hs,ws] fp32.  Outputs (each optional, at least one): probs, element
+ * (f,c,y,x) written at probs[f*probs_stride_n + c*probs_stride_c + y*W + x] (strides in elements: pass
+ * C*H*W, H*W for the reference's [n,C,H,W]; n_total*H*W as the channel stride stores all_P object-major);
+ * label_i64 / label_u8 / label_f32 [n,H,W] = argmax over channels (first maximum).                    */
+int ivosw_seg_epilogue(const float* logits, int n, int C, int hs, int ws, int H, int W, float* probs,
+                       long probs_stride_n, long probs_stride_c, int64_t* label_i64, uint8_t* label_u8,
+                       float* label_f32, ivosw_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks ---------- */
 /* Not part of the reference surface: bench.py's roofline leg.  Between start and stop every launch of
  * the dominant kernel family (conv_igemm*, conv1x1_wide*, conv3x3_patch*, bneck*, stem_pool*) is bracketed by hipEvents on the launch stream; stop

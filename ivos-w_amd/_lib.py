@@ -37,6 +37,7 @@ SIGNATURES = {
     "ivosw_assess_dominant_kernel": (C.c_char_p, [_i]),
     "ivosw_jf_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "ivosw_jf_counts": (_i, [_p, _p, _i, _i, _i, C.c_char_p, _i, _i, _p, _p, _sz, _p]),
+    "ivosw_seg_epilogue": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, C.c_long, C.c_long, _p, _p, _p, _p]),
     "ivosw_profile_start": (_i, []),
     "ivosw_profile_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "ivosw_profile_report": (_i, [C.c_char_p, _sz]),

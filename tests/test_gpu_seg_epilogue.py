@@ -1,0 +1,129 @@
+"""GPU parity: fused upsample + argmax + softmax epilogue (csrc/seg_epilogue.hip, ivos_w_amd.utils.utils_manet) vs the
+reference's own torch calls on the CPU (oracle/seg_oracle.py).
+
+Bars: probabilities within 2e-6 absolute of torch's (fp32 bilinear + exp: a few ulp); labels identical wherever the
+two best upsampled logits differ by more than 1e-5 (an argmax over fp32 values that agree to ~1e-7 can only flip at
+such near-ties; the test also bounds how many near-ties there are)."""
+import numpy as np
+import pytest
+import torch
+
+from ivos_w_amd.utils import utils_manet
+from oracle import seg_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def logits(k, C, hs, ws, seed):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(k, C, max(2, hs // 6), max(2, ws // 6), generator=g) * 3.0       # smooth blobs + fine noise
+    x = torch.nn.functional.interpolate(base, size=(hs, ws), mode="bicubic", align_corners=False)
+    return (x + 0.3 * torch.randn(k, C, hs, ws, generator=g)).contiguous()
+
+
+def check(lab, probs, x, h, w):
+    up, want_lab = so.epilogue(x, h, w)
+    want_p = torch.softmax(up, 1)
+    np.testing.assert_allclose(probs.cpu().numpy(), want_p.numpy(), rtol=0, atol=2e-6)
+    top2 = torch.topk(up, min(2, up.shape[1]), dim=1).values
+    gap = (top2[:, 0] - top2[:, -1]) if up.shape[1] > 1 else torch.ones_like(top2[:, 0])
+    clear = (gap > 1e-5).numpy()
+    got = lab.cpu().numpy()
+    assert (got[clear] == want_lab.numpy()[clear]).all()
+    assert (~clear).mean() < 1e-3
+    # at a near-tie either of the two best classes is acceptable
+    flip = got != want_lab.numpy()
+    assert not (flip & clear).any()
+    return flip.sum()
+
+
+@pytest.mark.parametrize("k,C,hs,ws,h,w", [
+    (3, 4, 120, 214, 480, 854),     # MANet: stride-4 logits, 3 objects + background
+    (1, 2, 120, 214, 480, 854),
+    (2, 8, 33, 47, 100, 131),       # odd sizes, CMAX = 8
+    (1, 11, 30, 40, 90, 120),       # CMAX = 16
+    (1, 20, 16, 16, 40, 56),        # generic (re-sampling) kernel
+    (2, 3, 1, 1, 5, 7),             # degenerate 1x1 source
+    (1, 3, 7, 9, 1, 1),             # degenerate 1x1 target (scale 0)
+    (1, 3, 12, 10, 12, 10),         # identity resampling
+])
+def test_epilogue_matches_torch_reference(dev, k, C, hs, ws, h, w):
+    x = logits(k, C, hs, ws, seed=k * 100 + C)
+    lab, probs = utils_manet.seg_epilogue(x.to(dev), h, w)
+    assert lab.dtype == torch.int64 and tuple(lab.shape) == (k, h, w) and tuple(probs.shape) == (k, C, h, w)
+    check(lab, probs, x, h, w)
+    s = probs.sum(1)
+    assert (s - 1).abs().max().item() < 1e-5
+
+
+def test_argmax_first_maximum_and_store_layout(dev):
+    x = torch.zeros(1, 3, 4, 4)
+    x[:, 1] = 1.0
+    x[:, 2] = 1.0                                   # exact tie between channels 1 and 2 everywhere
+    lab, probs = utils_manet.seg_epilogue(x.to(dev), 9, 9)
+    assert (lab == 1).all()                         # torch.argmax: first maximal value
+    store = utils_manet.ProbStore(5, 3, 9, 9, dev)
+    y = logits(2, 3, 4, 4, 7)
+    lab2, slot = utils_manet.seg_epilogue(y.to(dev), 9, 9, store, 2)
+    up, want = so.epilogue(y, 9, 9)
+    np.testing.assert_allclose(store.all_P[2:4].cpu().numpy(), torch.softmax(up, 1).numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_array_equal(slot.cpu().numpy(), store.all_P[2:4].cpu().numpy())
+    np.testing.assert_array_equal(store.labels_u8[2:4].cpu().numpy(), lab2.cpu().numpy())
+    np.testing.assert_array_equal(store.final_masks[2:4].cpu().numpy(), lab2.float().cpu().numpy())
+    # object-major storage: the per-object soft masks assess_all_objects takes are a contiguous view, not a copy
+    masks = store.all_P[:, 1:3].transpose(0, 1)
+    assert masks.reshape(2 * 5, 9, 9).data_ptr() == store.buf[1].data_ptr()
+
+
+class FakeMANet:
+    """Deterministic stand-in for the external MANet model: logits depend on the frame number, the embedding and the
+    previous label, so a wrong propagation order or a wrong label hand-over changes the result."""
+    dynamic_seghead = None
+
+    def __init__(self, C, hs, ws, dev):
+        g = torch.Generator().manual_seed(3)
+        self.basis = torch.randn(32, C, hs, ws, generator=g).to(dev)
+        self.C, self.hs, self.ws = C, hs, ws
+        self.calls = []
+
+    def _logits(self, frame, emb, prev_label):
+        x = self.basis[frame % 32] * 2.0 + emb.mean() * 0.1
+        if prev_label is not None:
+            pl = torch.nn.functional.interpolate(prev_label.float().reshape(1, 1, *prev_label.shape[-2:]), size=(self.hs, self.ws), mode="nearest")
+            x = x + 0.5 * torch.nn.functional.one_hot(pl.long()[0, 0], self.C).permute(2, 0, 1).float()
+        return x.unsqueeze(0)
+
+    def int_seghead(self, ref_frame_embedding, ref_scribble_label, prev_round_label, global_map_tmp_dic, local_map_dics,
+                    interaction_num, seq_names, gt_ids, frame_num, first_inter):
+        self.calls.append(("int", frame_num[0]))
+        return {seq_names[0]: self._logits(frame_num[0], ref_frame_embedding, None)}, local_map_dics
+
+    def prop_seghead(self, ref_emb, prev_emb, cur_emb, scribble_label, prev_label, normalize_nearest_neighbor_distances,
+                     use_local_map, seq_names, gt_ids, k_nearest_neighbors, global_map_tmp_dic, local_map_dics,
+                     interaction_num, start_annotated_frame, frame_num, dynamic_seghead):
+        self.calls.append(("prop", frame_num[0], k_nearest_neighbors))
+        return {seq_names[0]: self._logits(frame_num[0], cur_emb, prev_label)}, global_map_tmp_dic, local_map_dics
+
+
+def test_get_results_drop_in(dev):
+    n, C, hs, ws, h, w = 7, 4, 30, 53, 120, 212
+    emb = torch.randn(n, 8, 6, 6, generator=torch.Generator().manual_seed(1))
+    args = dict(scribble_label=None, prev_label=None, eval_global_map_tmp_dic={}, local_map_dics=({}, {}), n_interaction=1,
+                sequence="seq", obj_nums=C - 1, next_frame=3, first_scribble=True, h=h, w=w, total_frame_num=n)
+    m_gpu, m_cpu = FakeMANet(C, hs, ws, dev), FakeMANet(C, hs, ws, torch.device("cpu"))
+    st_gpu, st_cpu = {}, {}
+    fm, ap = utils_manet.get_results(m_gpu, emb[3:4].to(dev), prev_label_storage=st_gpu, embedding_memory=emb.to(dev), knns=5, **args)
+    fm_w, ap_w = so.get_results(m_cpu, emb[3:4], prev_label_storage=st_cpu, embedding_memory=emb, knns=5, **args)
+    assert m_gpu.calls == m_cpu.calls and m_gpu.calls[0] == ("int", 3) and m_gpu.calls[1] == ("prop", 4, 5)
+    assert tuple(fm.shape) == (n, h, w) and fm.dtype == torch.float32 and tuple(ap.shape) == (n, C, h, w)
+    np.testing.assert_array_equal(fm.cpu().numpy(), fm_w.numpy())       # smooth stand-in logits: no near-ties
+    np.testing.assert_allclose(ap.cpu().numpy(), ap_w.numpy(), atol=2e-6, rtol=0)
+    assert sorted(st_gpu) == sorted(st_cpu) == list(range(n))
+    for k in st_cpu:
+        np.testing.assert_array_equal(st_gpu[k].cpu().numpy(), st_cpu[k].numpy())
