@@ -20,11 +20,14 @@ constexpr int HD = 128;
 
 // ---------------------------------------------------------------- small kernels
 // a1[row][j] = relu(W1[j,:].x[row] + b1[j])        (encoder_fc1 + relu, agent.py:49)
-__global__ void enc1_kernel(const float* __restrict__ prm, const float* __restrict__ x, int rows, float* __restrict__ a1) {
+// rows [0, rows0) read x, rows [rows0, rows) read x2 (the policy pass runs [s'; s] as one batch without concatenating them)
+__global__ void enc1_kernel(const float* __restrict__ prm, const float* __restrict__ x, const float* __restrict__ x2, int rows0, int rows,
+                            float* __restrict__ a1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * HD) return;
     const int row = i >> 7, j = i & 127;
-    const float x0 = x[row * 2], x1 = x[row * 2 + 1];
+    const float* xr = row < rows0 ? x + (size_t)row * 2 : x2 + (size_t)(row - rows0) * 2;
+    const float x0 = xr[0], x1 = xr[1];
     const float v = fmaf(x1, prm[O_W1 + j * 2 + 1], fmaf(x0, prm[O_W1 + j * 2], prm[O_B1 + j]));
     a1[i] = fmaxf(v, 0.f);
 }
@@ -315,9 +318,11 @@ static int rows_per_wg(int rows) {
     return 4;
 }
 
-static void brain_forward_internal(const float* prm, const float* x, int N, int T, const FwdBufs& b, hipStream_t st) {
+// x2 != nullptr: samples [0, N0) come from x, [N0, N) from x2
+static void brain_forward_internal(const float* prm, const float* x, int N, int T, const FwdBufs& b, hipStream_t st,
+                                   const float* x2 = nullptr, int N0 = 0) {
     const int rows = N * T;
-    hipLaunchKernelGGL(enc1_kernel, dim3((rows * HD + 255) / 256), dim3(256), 0, st, prm, x, rows, b.a1);
+    hipLaunchKernelGGL(enc1_kernel, dim3((rows * HD + 255) / 256), dim3(256), 0, st, prm, x, x2 ? x2 : x, x2 ? N0 * T : rows, rows, b.a1);
     GemmF32 g{};
     // e = a1 * W2^T + b2
     g.A = b.a1; g.sam = 128; g.sak = 1; g.B = prm + O_W2; g.sbk = 1; g.sbn = 128; g.C = b.e; g.ldc = 128;
@@ -411,7 +416,27 @@ struct DqnWs {
     float *xcat, *dq, *dd1c, *w4term, *hcc, *dhc, *dG, *dgx, *de, *da1, *slabs;
 };
 
+int tune_get(const char* key, int dflt);   // capi.cpp
+
 static constexpr int WG_SPLIT = 16;
+
+// One helper stream + a few events per device, created on first use and kept for the life of the process.
+struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+};
+static Side* side_for_current_device() {
+    static Side sides[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Side& s = sides[dev];
+    if (!s.stream) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
+        for (auto& e : s.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &s;
+}
 
 static size_t dqn_ws_floats(int B, int T) {
     const size_t r = (size_t)B * T;
@@ -419,7 +444,7 @@ static size_t dqn_ws_floats(int B, int T) {
     n += 2 * r * 2;                        // xcat
     n += B + (size_t)B * 128 * 2 + (size_t)B * 256 * 2;  // dq, dd1c, w4term, hcc, dhc
     n += 2 * r * 512 + r * 512 + r * 128 + r * 128;       // dG, dgx, de, da1
-    n += (size_t)WG_SPLIT * 512 * 128;     // split-K slabs
+    n += 2 * (size_t)WG_SPLIT * 512 * 128; // split-K slabs, one set per stream
     return n + 64 * 32;
 }
 
@@ -501,12 +526,28 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     w.de = ar.take<float>((size_t)rows * 128);
     w.da1 = ar.take<float>((size_t)rows * 128);
     w.slabs = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
+    float* slabs2 = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
 
-    // ---- forward: policy on [s'; s] in one batch, target on s' (agent.py:135-137,144)
-    (void)hipMemcpyAsync(w.xcat, new_state, (size_t)rows * 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    (void)hipMemcpyAsync(w.xcat + (size_t)rows * 2, state, (size_t)rows * 2 * sizeof(float), hipMemcpyDeviceToDevice, st);
-    brain_forward_internal(policy, w.xcat, 2 * B, T, w.pol, st);
-    brain_forward_internal(target, new_state, B, T, w.tgt, st);
+    // The step is a chain of ~40 launches that each occupy a fraction of the chip for 5-30 us: independent branches run
+    // on a second stream (fork / join with events), so their kernels overlap instead of queueing behind each other.
+    Side* sd = tune_get("DQN_STREAMS", 1) ? side_for_current_device() : nullptr;
+    hipStream_t s2 = sd ? sd->stream : st;
+    auto fork = [&](int k) {          // s2 continues after everything enqueued on st so far
+        if (!sd) return;
+        (void)hipEventRecord(sd->ev[k], st);
+        (void)hipStreamWaitEvent(s2, sd->ev[k], 0);
+    };
+    auto join = [&](int k) {          // st continues after everything enqueued on s2 so far
+        if (!sd) return;
+        (void)hipEventRecord(sd->ev[k], s2);
+        (void)hipStreamWaitEvent(st, sd->ev[k], 0);
+    };
+
+    // ---- forward: policy on [s'; s] in one batch, target on s' (agent.py:135-137,144); the target pass runs beside it
+    fork(0);
+    brain_forward_internal(target, new_state, B, T, w.tgt, s2);
+    brain_forward_internal(policy, new_state, 2 * B, T, w.pol, st, state, B);
+    join(1);
 
     // ---- head: Double-DQN targets, loss, dL/dQsa (agent.py:136-151)
     const float* q_np = w.pol.q;
@@ -519,15 +560,8 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     const float* hs_s = w.pol.hs + (size_t)rows * 256;
     hipLaunchKernelGGL(dec_bwd_rows_kernel, dim3(B), dim3(128), 0, st, policy, w.dq, action, d1_s, hs_s, T, w.dd1c,
                        w.w4term, w.hcc);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.w4term, B, 128, 128, grads + O_W4);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.dd1c, B, 128, 128, grads + O_B3);
     GemmF32 g{};
-    // dW3[128,256] = dd1c^T * hcc
-    g.A = w.dd1c; g.sam = 1; g.sak = 128; g.B = w.hcc; g.sbk = 256; g.sbn = 1; g.C = grads + O_W3; g.ldc = 256;
-    g.M = 128; g.N = 256; g.K = B; g.splitk = 1;
-    launch_gemm_f32(g, st);
     // dhc[B,256] = (dd1c * W3) . (hcat > 0)
-    g = GemmF32{};
     g.A = w.dd1c; g.sam = 128; g.sak = 1; g.B = policy + O_W3; g.sbk = 256; g.sbn = 1; g.C = w.dhc; g.ldc = 256;
     g.M = B; g.N = 256; g.K = 128; g.mask = w.hcc; g.splitk = 1;
     launch_gemm_f32(g, st);
@@ -543,11 +577,6 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         else if (R == 2) hipLaunchKernelGGL(lstm_bwd_kernel<2>, dim3(nwg), dim3(512), 0, st, lb);
         else hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3(nwg), dim3(512), 0, st, lb);
     }
-    // dWhh[512,128] = sum_{d,n,t} dG^T * hprev          (K = 2*B*T)
-    g = GemmF32{};
-    g.A = w.dG; g.sam = 1; g.sak = 512; g.B = w.pol.hprev; g.sbk = 128; g.sbn = 1; g.ldc = 128;
-    g.M = 512; g.N = 128; g.K = 2 * rows;
-    launch_gemm_f32_splitk(g, grads + O_WHH, w.slabs, WG_SPLIT, st);
     // dgx = dG[fw] + dG[bw]  (the same e_t feeds both directions)
     {
         const size_t n = (size_t)rows * 512;
@@ -555,11 +584,28 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     }
     const float* e_s = w.pol.e + (size_t)rows * 128;
     const float* a1_s = w.pol.a1 + (size_t)rows * 128;
+
+    // ONE fork (every cross-stream event costs 7-13 us of stream time): the side stream takes the weight gradients whose
+    // operands exist by now (decoder, W_hh, W_ih: ~75 us), the main stream the dgrad chain down to the encoder (~100 us)
+    fork(2);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.w4term, B, 128, 128, grads + O_W4);
+    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.dd1c, B, 128, 128, grads + O_B3);
+    // dW3[128,256] = dd1c^T * hcc
+    g = GemmF32{};
+    g.A = w.dd1c; g.sam = 1; g.sak = 128; g.B = w.hcc; g.sbk = 256; g.sbn = 1; g.C = grads + O_W3; g.ldc = 256;
+    g.M = 128; g.N = 256; g.K = B; g.splitk = 1;
+    launch_gemm_f32(g, s2);
+    // dWhh[512,128] = sum_{d,n,t} dG^T * hprev          (K = 2*B*T)
+    g = GemmF32{};
+    g.A = w.dG; g.sam = 1; g.sak = 512; g.B = w.pol.hprev; g.sbk = 128; g.sbn = 1; g.ldc = 128;
+    g.M = 512; g.N = 128; g.K = 2 * rows;
+    launch_gemm_f32_splitk(g, grads + O_WHH, slabs2, WG_SPLIT, s2);
     // dWih[512,128] = dgx^T * e
     g = GemmF32{};
     g.A = w.dgx; g.sam = 1; g.sak = 512; g.B = e_s; g.sbk = 128; g.sbn = 1; g.ldc = 128;
     g.M = 512; g.N = 128; g.K = rows;
-    launch_gemm_f32_splitk(g, grads + O_WIH, w.slabs, WG_SPLIT, st);
+    launch_gemm_f32_splitk(g, grads + O_WIH, slabs2, WG_SPLIT, s2);
+
     // de[rows,128] = dgx * Wih
     g = GemmF32{};
     g.A = w.dgx; g.sam = 512; g.sak = 1; g.B = policy + O_WIH; g.sbk = 128; g.sbn = 1; g.C = w.de; g.ldc = 128;
@@ -582,6 +628,7 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     g.M = 128; g.N = 2; g.K = rows;
     launch_gemm_f32_splitk(g, grads + O_W1, w.slabs, WG_SPLIT, st);
     hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.da1, rows, 128, 128, grads + O_B1);
+    join(3);
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
