@@ -544,9 +544,10 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     };
 
     // ---- forward: policy on [s'; s] in one batch, target on s' (agent.py:135-137,144); the target pass runs beside it
+    // (host order matters: the policy chain is the critical path, so it is enqueued first)
     fork(0);
-    brain_forward_internal(target, new_state, B, T, w.tgt, s2);
     brain_forward_internal(policy, new_state, 2 * B, T, w.pol, st, state, B);
+    brain_forward_internal(target, new_state, B, T, w.tgt, s2);
     join(1);
 
     // ---- head: Double-DQN targets, loss, dL/dQsa (agent.py:136-151)
