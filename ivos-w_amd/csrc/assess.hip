@@ -265,6 +265,26 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                     q.ds = 1; q.fc = base + bp.cat_fw_off; q.bc = reinterpret_cast<const float*>(base + bp.cat_b_off);
                 }
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
+                if (bp.ds < 0 && bneck_wide_fusable(q) && bneck_stage_fusable(q) && b + 1 < nblk[s]) {
+                    // the rest of the stage is identity blocks of this shape: chain them inside one launch
+                    BneckStageArgs sa{};
+                    const char* xi = x;
+                    for (int bb = b; bb < nblk[s]; ++bb) {
+                        const BlockPlan& bq = P.blocks[first_blk[s] + bb];
+                        const ConvPlan &d1 = P.convs[bq.c1], &d2 = P.convs[bq.c2], &d3 = P.convs[bq.c3];
+                        char* yi = (bb == nblk[s] - 1) ? out : ((xi == bf.pa) ? bf.pb : bf.pa);
+                        BneckWideArgs& r = sa.blk[sa.n++];
+                        r = q;
+                        r.x = xi; r.y = yi;
+                        r.fa = base + bq.f1_off; r.ba = reinterpret_cast<const float*>(base + d1.b_off);
+                        r.fb = base + bq.f2_off; r.bb = reinterpret_cast<const float*>(base + d2.b_off);
+                        r.fc = base + bq.f3_off; r.bc = reinterpret_cast<const float*>(base + d3.b_off);
+                        xi = yi;
+                    }
+                    launch_bneck_wide_stage(sa, st);
+                    x = xi;
+                    break;
+                }
                 if (bneck_wide_fusable(q)) {
                     launch_bneck_wide(q, st);
                     x = y;

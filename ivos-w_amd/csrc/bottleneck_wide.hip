@@ -47,14 +47,13 @@ __device__ __forceinline__ void lgkm_wait() {
 // C = mid width (256: res4, 512: res5), HW = frame edge (16 / 8), FR = frames per workgroup (1 / 2): C * FR * HW^2 * 2 B
 // = 128 KB of t1 / t2 either way, and every wave owns CPW channel tiles x NPT pixel tiles = 8 accumulator tiles.
 template <int C, int HW, int FR>
-__global__ __launch_bounds__(512) void bneck_wide_kernel(BneckWideArgs p) {
+__device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned char* lds) {
     constexpr int CIN = 4 * C, NPX = FR * HW * HW, NPT = NPX / 32, NCT = C / 32, CPW = NCT / 8, NSL = C / 64;
     constexpr int SLICE = NPX * ROWB;                // one 64-channel slice of the pixel image
     constexpr int IMG_BYTES = NSL * SLICE, STG_OFF = IMG_BYTES;
     constexpr int HP = NPT / 2;                      // pixel tiles per rolling half
     static_assert(IMG_BYTES == 131072 && CPW * NPT == 8 && IMG_BYTES + 8 * 4096 == WIDE_LDS, "tile geometry");
     static_assert(4 * SLICE <= IMG_BYTES, "x ring: 4 slots");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];   // the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhalf = lane >> 5;
@@ -349,6 +348,33 @@ __global__ __launch_bounds__(512) void bneck_wide_kernel(BneckWideArgs p) {
     }
 }
 
+template <int C, int HW, int FR>
+__global__ __launch_bounds__(512) void bneck_wide_kernel(BneckWideArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];   // the ONLY LDS object
+    bneck_wide_body<C, HW, FR>(p, lds);
+}
+
+// A RUN of identity blocks in one launch: a workgroup owns a frame in every block, and the only consumer of a block's
+// output frame is the same workgroup in the next block — no inter-workgroup dependency, so the blocks of a stage can be
+// chained inside the kernel.  Saves the launch boundaries (drain + ramp of a 256-workgroup, single-wave grid) and lets
+// the workgroups drift apart, so that the HBM-heavy phases (A: x in, C: y out + residual) of some overlap the MFMA-heavy
+// phase B of others instead of all 256 CUs hitting HBM in lockstep.  Between blocks: a workgroup-scope release /
+// acquire pair around a barrier (the next block's x is what this workgroup just wrote, through other waves).
+template <int C, int HW, int FR>
+__global__ __launch_bounds__(512) void bneck_wide_stage_kernel(BneckStageArgs s) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];   // the ONLY LDS object
+    for (int j = 0; j < s.n; ++j) {
+        if (j > 0) {
+            // workgroup scope: producer and consumer waves share this CU's write-through L1 (an agent-scope release writes the
+            // XCD's whole L2 back each time: 1272 us for the 5-block run against 885 us as separate launches)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        bneck_wide_body<C, HW, FR>(s.blk[j], lds);
+    }
+}
+
 // ---------------------------------------------------------------- halo variant: res3 (C = 128, 32x32 frames) and res2 (C = 64, 64x64)
 // Same dataflow (wave-private fragment-ordered weights, t1 / t2 in LDS, transposed MFMAs), but the frame does not fit
 // one workgroup: a workgroup owns a 16x16-pixel tile and phase A computes t1 on its 18x18 halo (352 rows = 11 pixel
@@ -369,6 +395,10 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     constexpr int SLOT = NGA * 1024;                 // 41984 B per x K-tile
     constexpr int T1S = MH * ROWB, T2S = 256 * ROWB; // slice sizes of the t1 / t2 images
     constexpr int STG_OFF = 131072;
+    constexpr int BIAS_OFF = 3 * SLOT;               // ba | bb | bc as floats in the gap below the staging area instead of a global
+                                                     // load at the head of every epilogue / chunk (measured neutral here: 248 vs 254 us
+                                                     // within box variance; it mattered in the two-workgroup res2 kernel)
+    static_assert(BIAS_OFF + 6 * C * 4 <= STG_OFF, "bias block");
     static_assert(3 * SLOT <= STG_OFF && NSL * T1S <= STG_OFF && 2 * SLOT + MH * ROWB <= WIDE_LDS && TPG * (NG - 1) + TPG - 1 == 11, "geometry");
     __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -382,6 +412,9 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * HW * HW * CIN;
     const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
     const int ctw = wave % NCT, grp = wave / NCT;
+    if (tid < 2 * C) *reinterpret_cast<float*>(lds + BIAS_OFF + tid * 4) = tid < C ? p.ba[tid] : p.bb[tid - C];
+    if (tid < 4 * C) *reinterpret_cast<float*>(lds + BIAS_OFF + 2 * C * 4 + tid * 4) = p.bc[tid];      // visible after phase A's barriers
+    uint4 wn[4];                                     // first weight fragments of the next phase, requested one phase early
 
     // ================================================================ phase A: t1 = relu(Wa x + ba) on the halo, K = CIN
     {
@@ -459,9 +492,11 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         }
         __builtin_amdgcn_s_barrier();                // the ring is dead: its space becomes t1
         asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, 9 * C / 16, ks, lane);
         float4 bq[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.ba + ctw * 32 + 8 * g + 4 * lhalf);
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (ctw * 32 + 8 * g + 4 * lhalf) * 4);
 #pragma unroll
         for (int i = 0; i < TPG; ++i) {
             if (i == TPG - 1 && !full) break;
@@ -498,9 +533,6 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
             const int q = (grp * PB + i) * 32 + lrow;
             hb[i] = (q >> 4) * HT + (q & 15);
         }
-        uint4 wn[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, ks, lane);
 #pragma unroll 1
         for (int step = 0; step < NSTEP; ++step) {   // step = tap * NSL + slice
             const int tap = step / NSL, sl = step - tap * NSL;
@@ -540,9 +572,11 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         }
         __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
         asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, C / 16, ks, lane);
         float4 bq[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bb + ctw * 32 + 8 * g + 4 * lhalf);
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (C + ctw * 32 + 8 * g + 4 * lhalf) * 4);
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             const int px = (grp * PB + i) * 32 + lrow;
@@ -566,16 +600,17 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
         const int u = lane & 3, prr = lane >> 2;
         auto pix = [&](int q) { return (size_t)((y0 + (q >> 4)) * HW + x0 + (q & 15)) * CIN; };   // tile pixel q -> frame offset
-        uint4 wn[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, KSC, ks, lane);
 #pragma unroll 1
         for (int chunk = 0; chunk < NCH; ++chunk) {
             const int ct = chunk * 8 + wave;
+            const size_t cofs = (size_t)ct * 32 + 8 * u;
+            uint4 rr[2];                             // residual of the first pixel tile: in flight under the chunk's MFMAs
+#pragma unroll
+            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
             {
                 float4 bq[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bc + ct * 32 + 8 * g + 4 * lhalf);
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (2 * C + ct * 32 + 8 * g + 4 * lhalf) * 4);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -614,10 +649,6 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                     if (ks < 3) rd(ks + 1, 1);
                 }
             }
-            const size_t cofs = (size_t)ct * 32 + 8 * u;
-            uint4 rr[2];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -1198,6 +1229,19 @@ void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     else if (a.Cmid == 64) hipLaunchKernelGGL((bneck_halo_kernel<64>), dim3(a.B * 16), dim3(512), 0, st, a);
     else if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 2>), dim3(a.B / 2), dim3(512), 0, st, a);
+    prof_end(tok, st);
+}
+
+bool bneck_stage_fusable(const BneckWideArgs& a) { return !a.ds && a.Cmid == 256 && a.H == 16 && a.W == 16 && tune_get("STAGE_RUN", 1) != 0; }
+
+void launch_bneck_wide_stage(const BneckStageArgs& s_in, hipStream_t st) {
+    BneckStageArgs s = s_in;
+    const BneckWideArgs& a = s.blk[0];
+    ConvArgs d{};
+    d.B = a.B * s.n;                   // report row: n blocks x B frames of the same shape
+    d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
+    void* tok = prof_begin(d, 2, st);
+    hipLaunchKernelGGL((bneck_wide_stage_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, s);
     prof_end(tok, st);
 }
 

@@ -58,6 +58,13 @@ struct BneckWideArgs {
     int debug;                         // ablation bits (tunable BDBG; timing experiments only): 1 no y stores, 2 no residual
                                        // loads, 4 x DMA for the first K-tile only, 8 skip phase B, 16 skip phase A MFMAs
 };
+// a run of consecutive identity blocks of one stage (res4: one frame per workgroup) in ONE launch
+struct BneckStageArgs {
+    int n;
+    BneckWideArgs blk[6];
+};
+bool bneck_stage_fusable(const BneckWideArgs& a);
+void launch_bneck_wide_stage(const BneckStageArgs& s, hipStream_t st);
 bool bneck_wide_fusable(const BneckWideArgs& a);
 void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st);
 void launch_fragpack(const void* w, int Cout, int K, void* out, hipStream_t st);
