@@ -142,22 +142,28 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
     }
     // accumulators -> relu(acc + bias) -> bf16 -> image: channel tile ct lives in slice ct >> 1, chunks 4 * (ct & 1) + g
     auto store_img = [&](const float* bias) {
+        // the write addresses depend only on the lane: left alone, hipcc computes them once for both calls and keeps them
+        // live across phase B, i.e. spills them — and the second call then waits on ~15 serialised scratch reloads
+        // (21.5k cycles for the t2 store against 4.2k for the identical t1 store).  Laundering the lane ids makes each call
+        // recompute them.
+        int lrow_ = lrow, lhalf_ = lhalf;
+        asm volatile("" : "+v"(lrow_), "+v"(lhalf_));
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
             const int ct = wave * CPW + c;
             float4 bq[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bias + ct * 32 + 8 * g + 4 * lhalf);
+            for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bias + ct * 32 + 8 * g + 4 * lhalf_);
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
-                const int px = i * 32 + lrow;
+                const int px = i * 32 + lrow_;
                 const f32x16& a = acc[c * NPT + i];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 pk;
                     pk.x = pack2_bf16(fmaxf(a[4 * g] + bq[g].x, 0.f), fmaxf(a[4 * g + 1] + bq[g].y, 0.f));
                     pk.y = pack2_bf16(fmaxf(a[4 * g + 2] + bq[g].z, 0.f), fmaxf(a[4 * g + 3] + bq[g].w, 0.f));
-                    lds_write_b64(lds_base + (ct >> 1) * SLICE + px * ROWB + ((((ct & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                    lds_write_b64(lds_base + (ct >> 1) * SLICE + px * ROWB + ((((ct & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf_, pk);
                 }
             }
         }
