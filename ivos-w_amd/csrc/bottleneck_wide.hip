@@ -421,6 +421,13 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     if (tid < 2 * C) *reinterpret_cast<float*>(lds + BIAS_OFF + tid * 4) = tid < C ? p.ba[tid] : p.bb[tid - C];
     if (tid < 4 * C) *reinterpret_cast<float*>(lds + BIAS_OFF + 2 * C * 4 + tid * 4) = p.bc[tid];      // visible after phase A's barriers
     uint4 wn[4];                                     // first weight fragments of the next phase, requested one phase early
+    auto stamp = [&](int k) {
+        if (p.ts && tid == 0) p.ts[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    // (Tried: picking the residual of output chunk 0 out of the ring while its x K-tile is resident in phase A, to save
+    // re-reading half of x in phase C — 64 more live registers on top of phase A's 96 accumulator + 32 weight registers
+    // = 141 VGPR spills.  Dropped.)
 
     // ================================================================ phase A: t1 = relu(Wa x + ba) on the halo, K = CIN
     {
@@ -498,6 +505,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         }
         __builtin_amdgcn_s_barrier();                // the ring is dead: its space becomes t1
         asm volatile("" ::: "memory");
+        stamp(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, 9 * C / 16, ks, lane);
         float4 bq[4];
@@ -523,6 +531,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         lds_wait();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stamp(2);
     }
 
     // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x NSL slices
@@ -578,6 +587,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         }
         __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
         asm volatile("" ::: "memory");
+        stamp(3);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, C / 16, ks, lane);
         float4 bq[4];
@@ -597,6 +607,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         lds_wait();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stamp(4);
     }
 
     // ================================================================ phase C: y = relu(Wc t2 + bc + x), chunks of 8 channel tiles
@@ -655,6 +666,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                     if (ks < 3) rd(ks + 1, 1);
                 }
             }
+            if (chunk == NCH - 1) stamp(5);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -683,6 +695,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                 if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
             }
         }
+        stamp(6);
     }
 }
 

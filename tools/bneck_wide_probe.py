@@ -46,7 +46,7 @@ run(ts)
 torch.cuda.synchronize()
 t = ts.cpu().numpy().astype(np.float64)
 d = np.diff(t[:, :7], axis=1)
-names = ["A k-loop", "t1 store", "B taps", "t2 store", "C chunks 0-2 + mfma 3", "C last store pass"]
+names = ["A k-loop", "t1 store", "B taps", "t2 store", "C up to the last store pass", "C last store pass"]
 for i, n in enumerate(names):
     print(f"{n:24s} {d[:, i].mean():9.0f} {np.percentile(d[:, i], 10):8.0f} {np.percentile(d[:, i], 90):8.0f}")
 print(f"{'total':24s} {(t[:, 6] - t[:, 0]).mean():9.0f}   (shader clocks per workgroup)")
