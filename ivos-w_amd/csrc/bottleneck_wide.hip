@@ -76,6 +76,16 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
     // pixel-operand fragment reads in two rolling halves of the pixel tiles: the half just consumed is re-read for the
     // next k-step while the other half's MFMAs run
     u32x4 pf[NPT];
+    auto rd_tiles = [&](unsigned a, int half) {      // pixel tiles half*HP .. of the image row block at `a` (tile t = +t*4096 bytes)
+        static_assert(NPT == 8 || NPT == 4, "tile offsets are immediates");
+        if (NPT == 8) {
+            if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); pf[2] = lds_read_b128_o<8192>(a); pf[3] = lds_read_b128_o<12288>(a); }
+            else { pf[4] = lds_read_b128_o<16384>(a); pf[5] = lds_read_b128_o<20480>(a); pf[6] = lds_read_b128_o<24576>(a); pf[NPT - 1] = lds_read_b128_o<28672>(a); }
+        } else {
+            if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); }
+            else { pf[2] = lds_read_b128_o<8192>(a); pf[NPT - 1] = lds_read_b128_o<12288>(a); }
+        }
+    };
     auto mm_half = [&](const u32x4 (&w)[CPW], int half) {
 #pragma unroll
         for (int c = 0; c < CPW; ++c)
@@ -120,10 +130,12 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
             if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
             if (kt + 2 < NK) issue_x(kt + 2);
             const unsigned xb = lds_base + (kt & 3) * SLICE;
+            // pixel tile t of this lane = row t*32 + lrow: one swizzle key for all tiles -> one address per k-step, the tile
+            // as an immediate offset
+            const unsigned xrow = xb + lrow * ROWB;
             auto rd = [&](int ks, int half) {
-                const int ch = 2 * ks + lhalf;
-#pragma unroll
-                for (int i = 0; i < HP; ++i) pf[half * HP + i] = lds_read_b128(xb + swz((half * HP + i) * 32 + lrow, ch));
+                const unsigned a = xrow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                rd_tiles(a, half);
             };
             rd(0, 0);
             rd(0, 1);
@@ -294,10 +306,10 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
                         for (int c = 0; c < CPW; ++c) wn[ks][c] = *wfrag(p.fc, nct0 + c, KSC, nks + ks, lane);
                 }
                 const unsigned tb = lds_base + sl * SLICE;
+                const unsigned trow = tb + lrow * ROWB;
                 auto rd = [&](int ks, int half) {
-                    const int ch = 2 * ks + lhalf;
-#pragma unroll
-                    for (int i = 0; i < HP; ++i) pf[half * HP + i] = lds_read_b128(tb + swz((half * HP + i) * 32 + lrow, ch));
+                    const unsigned a = trow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                    rd_tiles(a, half);
                 };
                 rd(0, 0);
                 rd(0, 1);

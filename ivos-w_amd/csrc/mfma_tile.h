@@ -58,6 +58,15 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// same with a compile-time byte offset (<= 65535): fragment rows that differ by a multiple of 8 rows share the swizzle
+// key, so one address register per k-step + immediates replaces one register per (k-step, pixel tile) — which hipcc
+// otherwise hoists out of the K loop and, in the register-heavy kernels, spills
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128_o(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
 __device__ __forceinline__ void lds_write_b64(unsigned addr, u32x2 v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
