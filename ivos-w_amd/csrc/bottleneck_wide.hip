@@ -21,6 +21,8 @@
 //     written with ds_write_b64 and the final tile goes through a 4-KB per-wave staging tile to 64-B row segments.
 //
 // LDS: [0, 131072) x ring (4 x 32 KB) -> t1 -> t2 ; [131072, 163840) per-wave store staging (8 x 4 KB).
+#include <type_traits>
+
 #include "conv.h"
 #include "mfma_tile.h"
 
@@ -493,11 +495,18 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
             if (kt + 2 < NK) issue_x(kt + 2);        // slot (kt+2) % 3 == slot of tile kt-1: done for every wave
             const unsigned xb = lds_base + (kt % 3) * SLOT;
             u32x4 pf[TPG];
+            // pixel tile pt0 + t of this lane = row (pt0 + t)*32 + lrow: one swizzle key for every t -> one address per k-step,
+            // the tile as an immediate offset
+            const unsigned xrow = xb + (pt0 * 32 + lrow) * ROWB;
             auto rd = [&](int ks, int half) {
-                const int ch = 2 * ks + lhalf;
-#pragma unroll
-                for (int t = half ? HA0 : 0; t < (half ? TPG : HA0); ++t)
-                    if (t < TPG - 1 || full) pf[t] = lds_read_b128(xb + swz((pt0 + t) * 32 + lrow, ch));
+                const unsigned a = xrow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                auto one = [&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if (t >= (half ? HA0 : 0) && t < (half ? TPG : HA0) && (t < TPG - 1 || full)) pf[t] = lds_read_b128_o<t * 4096>(a);
+                };
+                one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+                if constexpr (TPG == 6) { one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{}); }
+                static_assert(TPG == 3 || TPG == 6, "tile offsets are immediates");
             };
             rd(0, 0);
             rd(0, 1);
@@ -659,10 +668,11 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                 }
                 const unsigned tb = lds_base + sl * T2S;
                 u32x4 pf[8];
+                const unsigned trow = tb + lrow * ROWB;
                 auto rd = [&](int ks, int half) {
-                    const int ch = 2 * ks + lhalf;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(tb + swz((half * 4 + i) * 32 + lrow, ch));
+                    const unsigned a = trow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                    if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); pf[2] = lds_read_b128_o<8192>(a); pf[3] = lds_read_b128_o<12288>(a); }
+                    else { pf[4] = lds_read_b128_o<16384>(a); pf[5] = lds_read_b128_o<20480>(a); pf[6] = lds_read_b128_o<24576>(a); pf[7] = lds_read_b128_o<28672>(a); }
                 };
                 rd(0, 0);
                 rd(0, 1);
@@ -806,10 +816,11 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
             if (kt == 1 && !(p.debug & 4)) issue_x(3);                 // slot 0: every wave is past K-tile 0
             const unsigned xb = lds_base + (kt % 3) * SLOT;
             u32x4 pf[2][2];
+            const unsigned xrow = xb + (grp * 32 + lrow) * ROWB;       // tile grp + 4 = + 16384 bytes, same swizzle key
             auto rd = [&](int ks, int buf) {
-                const int ch = 2 * ks + lhalf;
-                pf[buf][0] = lds_read_b128(xb + swz(grp * 32 + lrow, ch));
-                if (two) pf[buf][1] = lds_read_b128(xb + swz((grp + 4) * 32 + lrow, ch));
+                const unsigned a = xrow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                pf[buf][0] = lds_read_b128_o<0>(a);
+                if (two) pf[buf][1] = lds_read_b128_o<16384>(a);
             };
             rd(0, 0);
 #pragma unroll
@@ -960,10 +971,11 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
         }
         const unsigned tb = lds_base + T2_OFF;
         u32x4 pf[4];
+        const unsigned trow = tb + lrow * ROWB;
         auto rd = [&](int ks, int half) {
-            const int ch = 2 * ks + lhalf;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(tb + swz((half * 2 + i) * 32 + lrow, ch));
+            const unsigned a = trow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+            if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); }
+            else { pf[2] = lds_read_b128_o<8192>(a); pf[3] = lds_read_b128_o<12288>(a); }
         };
         rd(0, 0);
         rd(0, 1);
@@ -1126,10 +1138,11 @@ __global__ __launch_bounds__(512) void conv1x1_wide_kernel(ConvArgs p, const voi
                 if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
                 if (kt + 2 < NK) issue_x(kt + 2);
                 const unsigned xb = lds_base + (kt & 3) * SLICE;
+                const unsigned xrow = xb + lrow * ROWB;
                 auto rd = [&](int ks, int half) {
-                    const int ch = 2 * ks + lhalf;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pf[half * 4 + i] = lds_read_b128(xb + swz((half * 4 + i) * 32 + lrow, ch));
+                    const unsigned a = xrow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                    if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); pf[2] = lds_read_b128_o<8192>(a); pf[3] = lds_read_b128_o<12288>(a); }
+                    else { pf[4] = lds_read_b128_o<16384>(a); pf[5] = lds_read_b128_o<20480>(a); pf[6] = lds_read_b128_o<24576>(a); pf[7] = lds_read_b128_o<28672>(a); }
                 };
                 rd(0, 0);
                 rd(0, 1);
