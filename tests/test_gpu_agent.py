@@ -91,6 +91,34 @@ def test_loss_and_grads_vs_oracle(dev, B, T):
         assert np.abs(got[off:off + n] - want[off:off + n]).max() <= 1e-3 * s, k
 
 
+def test_step_is_deterministic_and_independent_of_the_side_stream(dev):
+    """The backward/forward branches of a DQN step run on two HIP streams (fork/join with events).  Same state, same
+    batch -> bit-identical loss and gradient arena, run after run, and identical to the single-stream schedule
+    (tunable DQN_STREAMS=0): no race, no atomics, fixed split-K order."""
+    from ivos_w_amd import _lib as L
+    from ivos_w_amd.models.agent import Agent
+    tr = synth.replay_transitions(n=600, T=25, seed=3)
+    agent = Agent(dev, cfg())
+    load_brain(agent.policy_net, 0)
+    load_brain(agent.target_net, 1)
+    lib = L.lib()
+    ref = None
+    try:
+        for streams in (1, 1, 0, 1, 0):
+            lib.ivosw_tune_set(b"DQN_STREAMS", streams)
+            for rep in range(3):
+                batch = synth.collate_np(tr, synth.minibatch_indices(rep, n=600, B=128, seed=5))
+                loss = agent.loss_and_grads(batch).cpu().numpy().copy()
+                g = agent.policy_net.flat_grad.cpu().numpy().copy()
+                if ref is None or len(ref) <= rep:
+                    ref = (ref or []) + [(loss, g)]
+                else:
+                    np.testing.assert_array_equal(loss, ref[rep][0])
+                    np.testing.assert_array_equal(g, ref[rep][1])
+    finally:
+        lib.ivosw_tune_set(b"DQN_STREAMS", 1)
+
+
 @pytest.mark.parametrize("B", [32, 128])
 def test_three_update_steps_vs_reference_golden(dev, golden_dir, B):
     from ivos_w_amd.models.agent import Agent
