@@ -13,11 +13,13 @@
 // This is integer / bit work bound by HBM (two label maps in) and latency: the kernels produce the six INTEGER counts per
 // (frame, object); the float64 ratios are formed on the host with the reference's own expressions, so results are
 // bit-identical whenever the counts are.
-//   jf_boundary_kernel  one thread = 32 pixels of one row: object masks of rows y, y+1 -> boundary words (bit-packed,
-//                       ws) + intersection / union / boundary-pixel counts (block reduce, one atomic per counter)
+//   jf_boundary_row_kernel  one lane = 16 pixels of a row (16-byte loads contiguous across the wave), four rows per wave:
+//                       object masks by a SWAR byte compare -> boundary words (bit-packed, ws) + intersection / union /
+//                       boundary-pixel counts (DPP wave reduction, one atomic per counter and block)
 //   jf_match_kernel     one thread = one boundary word of map A: skipped when empty (boundaries are sparse), otherwise
 //                       ORs the (2r+1) row-smears of map B around it (disk = per-row half widths) and counts A & dil(B)
 #include "common.h"
+#include <stdlib.h>
 
 namespace ivosw {
 
@@ -38,97 +40,125 @@ struct JfArgs {
     unsigned long long* counts;   // [N][n_obj][6]: inter, union, n_fg (pred boundary), n_gt, fg_match, gt_match
 };
 
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
 }  // namespace
 
-// 33 label bytes (this word's 32 pixels + the east neighbour of the last one) as 9 dwords.  Interior words take 9
-// unaligned dword loads (amdhsa runs with unaligned access mode; rows are not 4-byte aligned for W = 854); the last
-// word(s) of a row, which would read past the row end, assemble the bytes one by one and zero-fill beyond the image.
-__device__ __forceinline__ void load_labels(const uint8_t* row, int x0, int W, bool present, uint32_t (&w)[9]) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = 0u;
-    if (!present) return;
-    if (x0 + 36 <= W) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) __builtin_memcpy(&w[k], row + x0 + 4 * k, 4);
-    } else {
-        for (int k = 0; k < 33; ++k)
-            if (x0 + k < W) w[k >> 2] |= (uint32_t)row[x0 + k] << (8 * (k & 3));
-    }
+// Boundary kernel: a wave owns one row segment of up to 1024 pixels, lane l the 16 pixels [16 l, 16 l + 16) — the label
+// loads of a lane are 16-byte loads that are CONTIGUOUS across the wave (every byte used once).  East / south-east
+// neighbours come from the next lane; a lane pair forms one bitmap word.  History (100 frames x 3 objects at 480p):
+// one thread per 32-pixel word with 36-byte windows at a 32-byte lane stride 111 us -> this layout 94 us (the loads were
+// never the limit: the kernel is VALU-bound) -> two counters per 32-bit word through the reduction 57 us -> DPP instead
+// of ds_bpermute shuffles 53 us -> four rows per wave with the south row's masks reused 47 us.
+//
+// DPP cross-lane moves (one VALU instruction each; __shfl_down is a ds_bpermute plus address arithmetic, and this kernel
+// is VALU-bound).  wave_shl:1 = every lane reads lane + 1 (0 past the end); the reduction is the row_shr 1/2/4/8 scan
+// followed by row_bcast15 / row_bcast31, total in lane 63.
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_total_in_lane63(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8 -> lane 15 of each row holds the row sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast15 into rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast31 into rows 2, 3
+    return v;
 }
 
-// bit k = (label k == id), k = 0..32: SWAR zero-byte test on word ^ id, the four byte flags gathered by a multiply
-__device__ __forceinline__ uint64_t label_mask(const uint32_t (&w)[9], uint32_t id4, uint8_t id) {
-    uint64_t m = 0;
+__device__ __forceinline__ uint32_t mask16(const uint32_t (&w)[4], uint32_t id4) {
+    uint32_t m = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const uint32_t v = w[k] ^ id4;
-        const uint32_t t = ~((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) | 0x7F7F7F7Fu);    // 0x80 in every byte of v that is zero
-        const uint32_t nib = (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
-        m |= (uint64_t)nib << (4 * k);
+        const uint32_t t = ~((((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) | 0x7F7F7F7Fu);    // 0x80 in every zero byte of v
+        m |= ((((t >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);
     }
-    m |= (uint64_t)((w[8] & 0xFFu) == id) << 32;
     return m;
 }
 
-// Measured (100 frames, 3 objects, 480p): 111 us, of which the label loads are ~90 (with the loads ablated both kernels
-// together take 72 of 160 us).  Tried and dropped: staging the rows through LDS with lane-contiguous dword loads (210 us
-// for both kernels), four rows per thread with the south row reused (172 us: fewer loads but 4x fewer threads and 150
-// VGPRs — the loads are latency-, not count-bound).
-__global__ __launch_bounds__(256) void jf_boundary_kernel(JfArgs a) {
-    const int n = blockIdx.y;
-    const int item = blockIdx.x * 256 + threadIdx.x;
-    const int y = item / a.WW, j = item - y * a.WW;
-    const bool live = y < a.H;
-    const int x0 = j * 32;
-    // labels of this thread's 33 pixels in rows y and y+1 of both maps
-    uint32_t g0[9], g1[9], p0[9], p1[9];
-    {
-        const size_t ro = ((size_t)n * a.H + (live ? y : 0)) * a.W;
-        const bool has_s = live && y + 1 < a.H;
-        load_labels(a.gt + ro, x0, a.W, live, g0);
-        load_labels(a.pred + ro, x0, a.W, live, p0);
-        load_labels(a.gt + ro + a.W, x0, a.W, has_s, g1);
-        load_labels(a.pred + ro + a.W, x0, a.W, has_s, p1);
+__device__ __forceinline__ void load16(const uint8_t* base, size_t off, size_t total, bool on, uint32_t (&w)[4]) {
+    w[0] = w[1] = w[2] = w[3] = 0u;
+    if (!on) return;
+    if (off + 16 <= total) {
+        __builtin_memcpy(w, base + off, 16);          // bytes past the row end belong to the next row: masked by the caller
+    } else {
+        for (int k = 0; k < 16; ++k)
+            if (off + k < total) w[k >> 2] |= (uint32_t)base[off + k] << (8 * (k & 3));
     }
-    const int nvalid = live ? min(32, a.W - x0) : 0;                       // pixels of this word inside the image
-    const uint32_t vm = nvalid >= 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
-    const uint64_t vm33 = nvalid >= 32 ? ~0ull : ((1ull << nvalid) - 1ull);  // zero-filled bytes must not match id 0
-    const int lastbit = a.W - 1 - x0;                                       // bit of the last column, if in this word
-    const uint32_t lastcol = (lastbit >= 0 && lastbit < 32) ? (1u << lastbit) : 0u;
-    const bool lastrow = (y == a.H - 1);
+}
+
+// A wave walks JF_RPW consecutive rows: the south row of one step is the own row of the next, so JF_RPW + 1 row loads and
+// mask computations serve JF_RPW rows, and the counts are reduced once per object and wave (the kernel is VALU-bound).
+constexpr int JF_RPW = 4;
+__global__ __launch_bounds__(256) void jf_boundary_row_kernel(JfArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.z, seg = blockIdx.y;
+    const int y0 = (blockIdx.x * 4 + wave) * JF_RPW;
+    const int x0 = seg * 1024 + lane * 16;
+    const bool col_live = x0 < a.W;
+    const size_t total = (size_t)a.N * a.H * a.W;
+    uint32_t g[JF_RPW + 1][4], p[JF_RPW + 1][4];
+    uint8_t tg[JF_RPW + 1], tp[JF_RPW + 1];          // the pixel right of this lane's 16 at the end of a 1024-pixel segment
+    const bool tail = (lane == 63) && col_live && x0 + 16 < a.W;
+#pragma unroll
+    for (int r = 0; r <= JF_RPW; ++r) {
+        const int y = y0 + r;
+        const bool on = col_live && y < a.H;
+        const size_t off = ((size_t)n * a.H + (y < a.H ? y : 0)) * a.W + x0;
+        load16(a.gt, off, total, on, g[r]);
+        load16(a.pred, off, total, on, p[r]);
+        tg[r] = (tail && on) ? a.gt[off + 16] : 0;
+        tp[r] = (tail && on) ? a.pred[off + 16] : 0;
+    }
+    const int nvalid = col_live ? min(16, a.W - x0) : 0;
+    const uint32_t vm = (1u << nvalid) - 1u;
+    const int lastbit = a.W - 1 - x0;
+    const uint32_t lastcol = (lastbit >= 0 && lastbit < 16) ? (1u << lastbit) : 0u;
     __shared__ unsigned long long red[4][4];
     for (int o = 0; o < a.n_obj; ++o) {
-        unsigned long long c_int = 0, c_uni = 0, c_fg = 0, c_gt = 0;
-        if (live) {
-            const uint8_t id = a.ids[o];
-            const uint32_t id4 = id * 0x01010101u;
-            const uint64_t mg0 = label_mask(g0, id4, id) & vm33, mg1 = label_mask(g1, id4, id) & vm33;
-            const uint64_t mp0 = label_mask(p0, id4, id) & vm33, mp1 = label_mask(p1, id4, id) & vm33;
-            auto bmap = [&](uint64_t m0, uint64_t m1) {
-                const uint32_t seg = (uint32_t)m0, e = (uint32_t)(m0 >> 1), s = (uint32_t)m1, se = (uint32_t)(m1 >> 1);
+        const uint8_t id = a.ids[o];
+        const uint32_t id4 = id * 0x01010101u;
+        // bits 0..15 = this lane's pixels, bit 16 = the east neighbour of pixel 15 (rows >= H load zeros: no match for id > 0,
+        // and the valid mask clears id == 0 matches of rows that do not exist through `rows` below)
+        uint32_t mg[JF_RPW + 1], mp[JF_RPW + 1];
+#pragma unroll
+        for (int r = 0; r <= JF_RPW; ++r) {
+            const bool row_ok = y0 + r < a.H;
+            const uint32_t m0 = row_ok ? (mask16(g[r], id4) & vm) : 0u, m1 = row_ok ? (mask16(p[r], id4) & vm) : 0u;
+            const uint32_t e0 = lane == 63 ? ((tail && row_ok && tg[r] == id) ? 1u : 0u) : (lane_next(m0) & 1u);
+            const uint32_t e1 = lane == 63 ? ((tail && row_ok && tp[r] == id) ? 1u : 0u) : (lane_next(m1) & 1u);
+            mg[r] = m0 | (e0 << 16);
+            mp[r] = m1 | (e1 << 16);
+        }
+        uint32_t c01 = 0, c23 = 0;
+#pragma unroll
+        for (int r = 0; r < JF_RPW; ++r) {
+            const int y = y0 + r;
+            const bool lastrow = (y == a.H - 1);
+            auto bmap = [&](uint32_t m0, uint32_t m1) {
+                const uint32_t seg16 = m0 & 0xffffu, e = (m0 >> 1) & 0xffffu, s = m1 & 0xffffu, se = (m1 >> 1) & 0xffffu;
                 uint32_t b;
-                if (lastrow) b = (seg ^ e) & ~lastcol;                      // b[-1, :] = seg ^ e ; b[-1, -1] = 0
-                else b = (((seg ^ e) | (seg ^ s) | (seg ^ se)) & ~lastcol) | ((seg ^ s) & lastcol);   // b[:, -1] = seg ^ s
+                if (lastrow) b = (seg16 ^ e) & ~lastcol;                                   // b[-1, :] = seg ^ e ; b[-1, -1] = 0
+                else b = (((seg16 ^ e) | (seg16 ^ s) | (seg16 ^ se)) & ~lastcol) | ((seg16 ^ s) & lastcol);   // b[:, -1] = seg ^ s
                 return b & vm;
             };
-            const uint32_t bgw = bmap(mg0, mg1), bpw = bmap(mp0, mp1);
-            const size_t widx = (((size_t)o * a.N + n) * a.H + y) * a.WW + j;
-            a.bg[widx] = bgw;
-            a.bp[widx] = bpw;
-            const uint32_t sg = (uint32_t)mg0 & vm, sp = (uint32_t)mp0 & vm;
-            c_int = __popc(sg & sp);
-            c_uni = __popc(sg | sp);
-            c_fg = __popc(bpw);
-            c_gt = __popc(bgw);
+            const bool row_ok = y < a.H;
+            const uint32_t bgw = row_ok ? bmap(mg[r], mg[r + 1]) : 0u, bpw = row_ok ? bmap(mp[r], mp[r + 1]) : 0u;
+            // lanes 2k, 2k+1 -> bitmap word k of the segment
+            const uint32_t hg = lane_next(bgw), hp = lane_next(bpw);
+            if (row_ok && col_live && !(lane & 1)) {
+                const size_t widx = (((size_t)o * a.N + n) * a.H + y) * a.WW + (x0 >> 5);
+                a.bg[widx] = bgw | (hg << 16);
+                a.bp[widx] = bpw | (hp << 16);
+            }
+            const uint32_t sg = mg[r] & 0xffffu, sp = mp[r] & 0xffffu;
+            // each count is <= 16 per lane and row, <= 4096 per wave: two counters share one 32-bit word through the reduction
+            c01 += __popc(sg & sp) | (__popc(sg | sp) << 16);
+            c23 += __popc(bpw) | (__popc(bgw) << 16);
         }
-        c_int = wave_sum(c_int); c_uni = wave_sum(c_uni); c_fg = wave_sum(c_fg); c_gt = wave_sum(c_gt);
-        const int wave = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { red[wave][0] = c_int; red[wave][1] = c_uni; red[wave][2] = c_fg; red[wave][3] = c_gt; }
+        c01 = wave_total_in_lane63(c01);
+        c23 = wave_total_in_lane63(c23);
+        if (lane == 63) { red[wave][0] = c01 & 0xffffu; red[wave][1] = c01 >> 16; red[wave][2] = c23 & 0xffffu; red[wave][3] = c23 >> 16; }
         __syncthreads();
         if (threadIdx.x < 4) {
             const unsigned long long v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -152,36 +182,42 @@ __global__ __launch_bounds__(256) void jf_match_kernel(JfArgs a) {
         const uint32_t mine = own[(size_t)y * a.WW + j];
         if (mine) {
             uint32_t dil = 0;
-            for (int dy = -a.r; dy <= a.r; ++dy) {
-                const int yy = y + dy;
-                if (yy < 0 || yy >= a.H) continue;
-                const int w = a.hw[dy < 0 ? -dy : dy];
-                const uint32_t* row = oth + (size_t)yy * a.WW;
-                const uint64_t cur = row[j];
-                const uint64_t prev = j > 0 ? row[j - 1] : 0u;
-                const uint64_t next = j + 1 < a.WW ? row[j + 1] : 0u;
-                if (!(cur | prev | next)) continue;
-                // a set bit at x covers x-w .. x+w: smear towards higher x inside [prev | cur], towards lower x inside [cur | next]
-                uint64_t lo = prev | (cur << 32), hi = cur | (next << 32);
-                uint64_t sl = lo, sr = hi;
-                for (int covered = 0; covered < w;) {
-                    const int s = min(covered + 1, w - covered);
-                    sl |= sl << s;
-                    sr |= sr >> s;
-                    covered += s;
+            // rows in groups of 8: the 24 loads of a group are issued together (one dependent L2 round trip per group instead
+            // of one per row)
+            for (int d0 = -a.r; d0 <= a.r; d0 += 8) {
+                uint32_t cu[8], pv[8], nx[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int dy = d0 + k, yy = y + dy;
+                    const bool ok = dy <= a.r && yy >= 0 && yy < a.H;
+                    const uint32_t* row = oth + (size_t)(ok ? yy : y) * a.WW;
+                    cu[k] = ok ? row[j] : 0u;
+                    pv[k] = (ok && j > 0) ? row[j - 1] : 0u;
+                    nx[k] = (ok && j + 1 < a.WW) ? row[j + 1] : 0u;
                 }
-                dil |= (uint32_t)(sl >> 32) | (uint32_t)sr;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (!(cu[k] | pv[k] | nx[k])) continue;
+                    const int dy = d0 + k;
+                    const int w = a.hw[dy < 0 ? -dy : dy];
+                    // a set bit at x covers x-w .. x+w: smear towards higher x inside [prev | cur], towards lower x inside [cur | next]
+                    uint64_t sl = (uint64_t)pv[k] | ((uint64_t)cu[k] << 32), sr = (uint64_t)cu[k] | ((uint64_t)nx[k] << 32);
+                    for (int covered = 0; covered < w;) {
+                        const int sh = min(covered + 1, w - covered);
+                        sl |= sl << sh;
+                        sr |= sr >> sh;
+                        covered += sh;
+                    }
+                    dil |= (uint32_t)(sl >> 32) | (uint32_t)sr;
+                }
             }
             c = __popc(mine & dil);
         }
     }
-    c = wave_sum(c);
-    __shared__ unsigned long long red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long v = red[0] + red[1] + red[2] + red[3];
-        if (v) atomicAdd(a.counts + ((size_t)n * a.n_obj + o) * 6 + 4 + blockIdx.z, v);
+    // boundaries are sparse: most waves have nothing to add and skip the reduction; a word contributes <= 32
+    if (__ballot(c != 0) != 0ull) {
+        const uint32_t t = wave_total_in_lane63((uint32_t)c);
+        if ((threadIdx.x & 63) == 63 && t) atomicAdd(a.counts + ((size_t)n * a.n_obj + o) * 6 + 4 + blockIdx.z, (unsigned long long)t);
     }
 }
 
@@ -201,6 +237,7 @@ extern "C" int ivosw_jf_counts(const uint8_t* gt, const uint8_t* pred, int N, in
     IVOSW_REQUIRE(N > 0 && H > 0 && W > 0, "N, H, W must be positive");
     IVOSW_REQUIRE(n_obj > 0 && n_obj <= JF_MAX_OBJ, "1..32 object ids");
     IVOSW_REQUIRE((long)N * n_obj <= 65535, "N * n_obj must fit one grid dimension (65535): split the sequence");
+    IVOSW_REQUIRE(W <= 65535 * 16, "image too wide");
     IVOSW_REQUIRE(bound_pix >= 0 && bound_pix <= JF_MAX_R, "boundary tolerance 0..32 pixels");
     if (ws_bytes < ivosw_jf_ws_bytes(N, H, W, n_obj)) {
         set_error("ivosw_jf_counts: workspace %zu < %zu", ws_bytes, ivosw_jf_ws_bytes(N, H, W, n_obj));
@@ -221,7 +258,7 @@ extern "C" int ivosw_jf_counts(const uint8_t* gt, const uint8_t* pred, int N, in
     a.counts = reinterpret_cast<unsigned long long*>(counts);
     (void)hipMemsetAsync(counts, 0, (size_t)N * n_obj * 6 * sizeof(int64_t), st);
     const unsigned nblk = (unsigned)(((size_t)H * a.WW + 255) / 256);
-    hipLaunchKernelGGL(jf_boundary_kernel, dim3(nblk, N), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(jf_boundary_row_kernel, dim3((H + 4 * JF_RPW - 1) / (4 * JF_RPW), (W + 1023) / 1024, N), dim3(256), 0, st, a);
     hipLaunchKernelGGL(jf_match_kernel, dim3(nblk, N * n_obj, 2), dim3(256), 0, st, a);
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;

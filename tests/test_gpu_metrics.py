@@ -49,6 +49,10 @@ def test_hand_cases_on_device(dev):
     (1, 9, 100, 1, 0.008),
     (2, 200, 300, 4, 20),         # wide disk: smears cross word borders by 20 px
     (2, 33, 32, 1, 32),           # the largest supported radius
+    (1, 21, 1100, 2, 4),          # wider than one 1024-pixel wave segment: the east neighbour crosses segments
+    (1, 9, 1024, 1, 2),           # exactly one segment
+    (1, 9, 1025, 1, 2),           # one pixel in the second segment
+    (2, 17, 16, 1, 1),            # a single lane per row
 ])
 def test_counts_and_metrics_match_oracle(dev, N, H, W, O, bth):
     gt, pr = synth.label_maps(N, H, W, O, seed=N * 1000 + W, void=(O > 1))
