@@ -45,7 +45,9 @@ __device__ __forceinline__ float sample(const float* __restrict__ p, int ws, int
 // CMAX > 0: channel values live in registers (C <= CMAX); CMAX == 0: any C, channels re-sampled per pass.
 // V = pixels per thread (consecutive in the H*W plane): V = 4 turns every output stream into 16-byte (labels: 32 / 4 /
 // 16-byte) stores; it needs H*W and the probability strides to be multiples of 4, otherwise V = 1.
-template <int CMAX, int V>
+// FULL: C == CMAX, the per-channel guards disappear (1090 VALU instructions per wave made this kernel VALU-bound: the
+// guards, 64-bit index arithmetic and a 64-bit division per pixel were a third of them).
+template <int CMAX, int V, bool FULL = false>
 __global__ __launch_bounds__(256) void seg_epilogue_kernel(SegArgs a) {
     // no FMA contraction: fma(rw, x, -floor) keeps the exact product and moves the interpolation weight by an ulp of the
     // SOURCE coordinate (1.5e-5 at x ~ 200), i.e. the logits by ~3e-5 — ATen rounds scale * index to fp32 first
@@ -53,8 +55,10 @@ __global__ __launch_bounds__(256) void seg_epilogue_kernel(SegArgs a) {
     // after inlining no matter what the caller says, so the arithmetic below uses bare operators under this pragma)
 #pragma clang fp contract(off)
     const int f = blockIdx.y;
-    const long idx0 = ((long)blockIdx.x * 256 + threadIdx.x) * V;
-    if (idx0 >= (long)a.H * a.W) return;
+    const unsigned idx0 = (blockIdx.x * 256u + threadIdx.x) * V;          // H * W < 2^31 (checked by the launcher)
+    if (idx0 >= (unsigned)(a.H * a.W)) return;
+    const int C = FULL ? CMAX : a.C;
+    unsigned yy = idx0 / (unsigned)a.W, xx = idx0 - yy * (unsigned)a.W;      // pixel p: (yy, xx), advanced incrementally
     const float* base = a.logits + (size_t)f * a.C * a.hs * a.ws;
     const size_t plane = (size_t)a.hs * a.ws;
     constexpr int CR = CMAX > 0 ? CMAX : 1;
@@ -62,8 +66,9 @@ __global__ __launch_bounds__(256) void seg_epilogue_kernel(SegArgs a) {
     int am[V];
 #pragma unroll
     for (int p = 0; p < V; ++p) {
-        const long idx = idx0 + p;
-        const int y = (int)(idx / a.W), x = (int)(idx - (long)y * a.W);
+        const unsigned idx = idx0 + p;
+        const int y = (int)yy, x = (int)xx;
+        if (++xx == (unsigned)a.W) { xx = 0; ++yy; }
         const float h1r = a.rh * (float)y, w1r = a.rw * (float)x;
         const int h1 = (int)h1r, w1 = (int)w1r;
         const int h1p = h1 < a.hs - 1 ? 1 : 0, w1p = w1 < a.ws - 1 ? 1 : 0;
@@ -73,31 +78,35 @@ __global__ __launch_bounds__(256) void seg_epilogue_kernel(SegArgs a) {
         am[p] = 0;
         if (CMAX > 0) {
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) pv[c][p] = c < a.C ? sample(base + c * plane, a.ws, h1, h1p, w1, w1p, h0l, h1l, w0l, w1l) : 0.f;
+            for (int c = 0; c < CMAX; ++c) pv[c][p] = c < C ? sample(base + c * plane, a.ws, h1, h1p, w1, w1p, h0l, h1l, w0l, w1l) : 0.f;
             best = pv[0][p];
 #pragma unroll
             for (int c = 1; c < CMAX; ++c)
-                if (c < a.C && pv[c][p] > best) { best = pv[c][p]; am[p] = c; }
+                if (c < C && pv[c][p] > best) { best = pv[c][p]; am[p] = c; }
             if (a.probs) {
+                // VALU-bound kernel: exp through the hardware exp2 (v_exp_f32; arguments are <= 0, the absolute error stays
+                // below 1e-7) and ONE reciprocal per pixel instead of C IEEE divisions — inside the 2e-6 bar against
+                // torch.softmax (the generic-C kernel below keeps expf and the division)
                 float s = 0.f;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
-                    if (c < a.C) { pv[c][p] = expf(pv[c][p] - best); s += pv[c][p]; }
+                    if (c < C) { pv[c][p] = __expf(pv[c][p] - best); s += pv[c][p]; }
+                const float inv = 1.0f / s;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
-                    if (c < a.C) pv[c][p] = pv[c][p] / s;
+                    if (c < C) pv[c][p] = pv[c][p] * inv;
             }
         } else {
             best = sample(base, a.ws, h1, h1p, w1, w1p, h0l, h1l, w0l, w1l);
-            for (int c = 1; c < a.C; ++c) {
+            for (int c = 1; c < C; ++c) {
                 const float v = sample(base + c * plane, a.ws, h1, h1p, w1, w1p, h0l, h1l, w0l, w1l);
                 if (v > best) { best = v; am[p] = c; }
             }
             if (a.probs) {
                 float s = 0.f;
-                for (int c = 0; c < a.C; ++c) s += expf(sample(base + c * plane, a.ws, h1, h1p, w1, w1p, h0l, h1l, w0l, w1l) - best);
+                for (int c = 0; c < C; ++c) s += expf(sample(base + c * plane, a.ws, h1, h1p, w1, w1p, h0l, h1l, w0l, w1l) - best);
                 float* out = a.probs + (size_t)f * a.sn + idx;
-                for (int c = 0; c < a.C; ++c)
+                for (int c = 0; c < C; ++c)
                     out[(size_t)c * a.sc] = expf(sample(base + c * plane, a.ws, h1, h1p, w1, w1p, h0l, h1l, w0l, w1l) - best) / s;
             }
         }
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void seg_epilogue_kernel(SegArgs a) {
         float* out = a.probs + (size_t)f * a.sn + idx0;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-            if (c < a.C) {
+            if (c < C) {
                 if (V == 4) *reinterpret_cast<float4*>(out + (size_t)c * a.sc) = make_float4(pv[c][0], pv[c][1], pv[c][2], pv[c][V - 1]);
                 else out[(size_t)c * a.sc] = pv[c][0];
             }
@@ -135,6 +144,7 @@ extern "C" int ivosw_seg_epilogue(const float* logits, int n, int C, int hs, int
     IVOSW_REQUIRE(logits, "null logits");
     IVOSW_REQUIRE(probs || label_i64 || label_u8 || label_f32, "no output requested");
     IVOSW_REQUIRE(n > 0 && n <= 65535 && C > 0 && hs > 0 && ws > 0 && H > 0 && W > 0, "bad shape");
+    IVOSW_REQUIRE((long)H * W < (1L << 31) && (long)C * hs * ws < (1L << 31), "frame too large for 32-bit pixel indices");
     IVOSW_REQUIRE(!label_u8 || C <= 256, "uint8 labels need C <= 256");
     IVOSW_REQUIRE(!probs || (probs_stride_c >= (long)H * W && probs_stride_n >= (long)H * W), "probability strides overlap");
     SegArgs a{};
@@ -150,7 +160,8 @@ extern "C" int ivosw_seg_epilogue(const float* logits, int n, int C, int hs, int
     const dim3 grid((unsigned)((items + 255) / 256), n);
 #define IVOSW_SEG_LAUNCH(CM)                                                                                   \
     do {                                                                                                       \
-        if (vec) hipLaunchKernelGGL((seg_epilogue_kernel<CM, 4>), grid, dim3(256), 0, st, a);                  \
+        if (vec && C == CM) hipLaunchKernelGGL((seg_epilogue_kernel<CM, 4, true>), grid, dim3(256), 0, st, a); \
+        else if (vec) hipLaunchKernelGGL((seg_epilogue_kernel<CM, 4>), grid, dim3(256), 0, st, a);             \
         else hipLaunchKernelGGL((seg_epilogue_kernel<CM, 1>), grid, dim3(256), 0, st, a);                      \
     } while (0)
     if (C <= 4) IVOSW_SEG_LAUNCH(4);
