@@ -15,6 +15,8 @@
 // MFMA view ("transposed": A = filters, B = pixels, so a lane holds 4 consecutive channels of one pixel):
 //   channels 64 = 2 tiles, conv pixels 289 -> 10 tiles of 32, K = 7 filter rows x 8 taps x 4 channels = 14 steps of 16
 //   (tap 7 of every filter row carries zero weights; the patch has a 40th zero column for it).
+#include <type_traits>
+
 #include "conv.h"
 #include "mfma_tile.h"
 
@@ -107,23 +109,32 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int g = 0; g < 4; ++g) {            // accumulators start at the bias: no add in the epilogue
+                acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+            }
         {
             u32x4 wf[2], pf[2][5];
-            auto frag_read = [&](int s, int buf) {       // step s: filter row s >> 1, taps 4*(s&1) .. +3
-                const int ky = s >> 1, h2 = s & 1;
-                wf[buf] = lds_read_b128(wb + ((ky * 4 + 2 * h2) * 64) * 16);
+            // step S: filter row S >> 1, taps 4*(S&1) .. +3; the per-step offsets are immediates of the ds_read (the kernel is
+            // VALU-bound: ~820 non-MFMA vector instructions per tile against 70 MFMAs, a fifth of them address adds)
+            auto frag_read = [&](auto sc, int buf) {
+                constexpr int S = decltype(sc)::value, ky = S >> 1, h2 = S & 1;
+                wf[buf] = lds_read_b128_o<((ky * 4 + 2 * h2) * 64) * 16>(wb);
 #pragma unroll
-                for (int i = 0; i < 5; ++i) pf[buf][i] = lds_read_b128(pb[i] + ky * (PW * 8) + h2 * 32);
+                for (int i = 0; i < 5; ++i) pf[buf][i] = lds_read_b128_o<ky * (PW * 8) + h2 * 32>(pb[i]);
             };
-            frag_read(0, 0);
-#pragma unroll
-            for (int s = 0; s < 14; ++s) {
+            auto step = [&](auto sc) {
+                constexpr int S = decltype(sc)::value;
                 lds_wait();
-                if (s < 13) frag_read(s + 1, (s + 1) & 1);
+                if constexpr (S < 13) frag_read(std::integral_constant<int, S + 1>{}, (S + 1) & 1);
 #pragma unroll
-                for (int i = 0; i < 5; ++i) acc[i] = mfma_bf16(wf[s & 1], pf[s & 1][i], acc[i]);
-            }
+                for (int i = 0; i < 5; ++i) acc[i] = mfma_bf16(wf[S & 1], pf[S & 1][i], acc[i]);
+            };
+            frag_read(std::integral_constant<int, 0>{}, 0);
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+            step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+            step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
         }
         // + bias, ReLU, zero outside the 128x128 conv map (pool padding: every window holds a valid value >= 0)
 #pragma unroll
@@ -135,8 +146,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
                 const bool in = cy >= 0 && cy < 128 && cx >= 0 && cx < 128;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float v0 = fmaxf(acc[i][4 * g] + bq[g].x, 0.f), v1 = fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f);
-                    const float v2 = fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), v3 = fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f);
+                    // ReLU as ONE instruction: fmaxf(x, 0) on a raw MFMA result costs a second v_max that only quiets NaNs
+                    // (hipcc lowers fmed3 the same way), so the v_max is spelled out
+                    auto relu1 = [](float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; };
+                    const float v0 = relu1(acc[i][4 * g]), v1 = relu1(acc[i][4 * g + 1]);
+                    const float v2 = relu1(acc[i][4 * g + 2]), v3 = relu1(acc[i][4 * g + 3]);
                     uint2 pk;
                     pk.x = in ? pack2_bf16(v0, v1) : 0u;
                     pk.y = in ? pack2_bf16(v2, v3) : 0u;
