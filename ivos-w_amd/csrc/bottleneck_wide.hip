@@ -803,17 +803,17 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
         load_w(0);
         if (NKA > 1) load_w(1);
         issue_x(0);
-        if (NKA > 1 && !(p.debug & 4)) { issue_x(1); issue_x(2); }
+        if (NKA > 1) { issue_x(1); issue_x(2); }
 #pragma unroll
         for (int kt = 0; kt < NKA; ++kt) {
             // in-order queue: W0 W1 X0 X1 X2 | W2 X3 (iteration 1) | W3 (iteration 2): younger than {W(kt), X(kt)} are
             // X1 X2 | X2 | X3 | nothing
-            if ((p.debug & 4) || NKA == 1) wait_vmcnt<0>(); else
+            if (NKA == 1) wait_vmcnt<0>(); else
             if (kt == 0) wait_vmcnt_n(2 * np); else if (kt < 3) wait_vmcnt_n(np); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kt == 1 || kt == 2) load_w(kt + 1); // set (kt+1) & 1 held K-tile kt-1
-            if (kt == 1 && !(p.debug & 4)) issue_x(3);                 // slot 0: every wave is past K-tile 0
+            if (kt == 1) issue_x(3);                 // slot 0: every wave is past K-tile 0
             const unsigned xb = lds_base + (kt % 3) * SLOT;
             u32x4 pf[2][2];
             const unsigned xrow = xb + (grp * 32 + lrow) * ROWB;       // tile grp + 4 = + 16384 bytes, same swizzle key
@@ -827,7 +827,6 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks < 3) rd(ks + 1, (ks + 1) & 1);
                 if (ks < 3) { if (two) lgkm_wait<2>(); else lgkm_wait<1>(); } else lgkm_wait<0>();
-                if (p.debug & 16) continue;
                 acc[0] = mfma_bf16(wq[kt & 1][ks], pf[ks & 1][0], acc[0]);
                 if (two) acc[1] = mfma_bf16(wq[kt & 1][ks], pf[ks & 1][1], acc[1]);
             }
@@ -880,7 +879,6 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
         const int k0 = kh * 18;
 #pragma unroll
         for (int c6 = 0; c6 < 3; ++c6) {
-            if (p.debug & 8) break;
             u32x4 wc[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) wc[j] = as_u32x4(wnb[j]);
@@ -957,7 +955,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
         const size_t cofs = (size_t)wave * 32 + 8 * u;
         uint4 rr[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) rr[it] = (DS || (p.debug & 2)) ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
+        for (int it = 0; it < 2; ++it) rr[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
         {
             float4 bq[4];
 #pragma unroll
@@ -1031,7 +1029,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
             uint4 rn[2];
             if (i < 3) {
 #pragma unroll
-                for (int it = 0; it < 2; ++it) rn[it] = (DS || (p.debug & 2)) ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix((i + 1) * 32 + it * 16 + prr) + cofs);
+                for (int it = 0; it < 2; ++it) rn[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix((i + 1) * 32 + it * 16 + prr) + cofs);
             }
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -1044,7 +1042,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
-                if (!(p.debug & 1) || pk[0] == 0x12345678u) *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
             if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
         }

@@ -55,8 +55,8 @@ struct BneckWideArgs {
     int B, H, W, Cin, Cmid;
     unsigned long long* ts;            // optional [B][8] s_memtime stamps at the phase boundaries (ivosw_bneck_wide_probe)
     int ds;                            // 1: first block of res2 (Cin = Cmid = 64): fc = [conv3 | downsample] along K (K = 128), bc = bias sum
-    int debug;                         // ablation bits (tunable BDBG; timing experiments only): 1 no y stores, 2 no residual
-                                       // loads, 4 x DMA for the first K-tile only, 8 skip phase B, 16 skip phase A MFMAs
+    int debug;                         // (unused by the current kernels; the ablation bits of the res2 experiments were removed
+                                       // again: ~20 branches in a kernel that is instruction-issue-bound)
 };
 // a run of consecutive identity blocks of one stage (res4: one frame per workgroup) in ONE launch
 struct BneckStageArgs {
