@@ -740,6 +740,13 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
     constexpr int BAB_OFF = DS ? SLOT + 23040 : STG_OFF + 32768, BC_OFF = DS ? 23552 : BAB_OFF + 512;
     constexpr int LDS_BYTES = STG_OFF + 32768 + (DS ? 0 : 1536);   // 75264 | 81920: two workgroups per CU either way
     constexpr int TPXX = HW / BTX, TPF = (HW / BTY) * TPXX;   // 4 tiles across, 32 per frame
+    // t1 rows: the identity kernel pads them to 144 B instead of XOR-swizzling the 16-byte chunks — consecutive rows then sit
+    // 36 banks apart (conflict-free for the 16-lane groups of a ds_read_b128), and a phase-B fragment address becomes
+    // "row base + compile-time offset": no per-read arithmetic (216 vector instructions per tile in a kernel that is
+    // instruction-issue-bound).  180 x 144 B = 25 920 B runs 1 344 B into the t2 area, which is only written once every
+    // wave is done reading t1.  (DS keeps the swizzle: its LDS map has no spare bytes next to t1.)
+    constexpr bool PAD = !DS;
+    constexpr int T1R = PAD ? 144 : ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
     stamp(0);
     float bias_v = 0.f;                              // thread t: ba[t] | bb[t - 64] | bc[t - 128]
     if (tid < 64) bias_v = p.ba[tid]; else if (tid < 128) bias_v = p.bb[tid - 64]; else if (tid < 384) bias_v = p.bc[tid - 128];
-    uint4 wnb[6], wnc[4], wd[4];                     // first weight fragments of phases B and C, requested one phase early
+    uint4 wnb[3], wnb2[3], wnc[4], wd[4];            // weight fragments of phases B (two alternating sets) and C, requested early
     float4 bq[4];                                    // conv1 bias of this wave's channel tile (registers: used before the LDS copy is visible)
 #pragma unroll
     for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.ba + ctw * 32 + 8 * g + 4 * lhalf);
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
         if (tid < 128) *reinterpret_cast<float*>(lds + BAB_OFF + tid * 4) = bias_v;
         else if (tid < 384) *reinterpret_cast<float*>(lds + BC_OFF + (tid - 128) * 4) = bias_v;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) wnb[j] = *wfrag(p.fb, ctw, 36, (wave >> 2) * 18 + j, lane);
+        for (int j = 0; j < 3; ++j) wnb[j] = *wfrag(p.fb, ctw, 36, (wave >> 2) * 18 + j, lane);
 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -852,7 +859,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
                     u32x2 pk;
                     pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
                     pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
-                    lds_write_b64(lds_base + T1_OFF + hr * ROWB + (((ctw * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                    if (PAD) lds_write_b64(lds_base + T1_OFF + hr * T1R + ((ctw * 4 + g) << 4) + 8 * lhalf, pk);
+                    else lds_write_b64(lds_base + T1_OFF + hr * ROWB + (((ctw * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
             }
         }
@@ -876,36 +884,51 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
             const int q = (pp * 2 + i) * 32 + lrow;
             hb[i] = (q >> 4) * HTX + (q & 15);
         }
-        const int k0 = kh * 18;
+        // the K half is a compile-time constant inside (one runtime branch on wave >> 2): taps and k-steps of every read
+        // are then constants, the weight sets alternate without register copies
+        unsigned rb[2];
 #pragma unroll
-        for (int c6 = 0; c6 < 3; ++c6) {
-            u32x4 wc[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) wc[j] = as_u32x4(wnb[j]);
-            if (c6 < 2) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) wnb[j] = *wfrag(p.fb, ctw, 36, k0 + (c6 + 1) * 6 + j, lane);
-            }
+        for (int i = 0; i < 2; ++i) rb[i] = lds_base + T1_OFF + hb[i] * T1R + lhalf * 16;
+        auto run_half = [&](auto khc) {
+            constexpr int K0 = decltype(khc)::value * 18;
             u32x4 pf[2][2];
-            auto rd = [&](int j, int buf) {
-                const int kstep = k0 + c6 * 6 + j;
-                const int tap = kstep >> 2, ch = 2 * (kstep & 3) + lhalf;
-                const int toff = (tap / 3) * HTX + (tap % 3);
+            auto rd = [&](auto kc, int buf) {
+                constexpr int kstep = K0 + decltype(kc)::value;
+                constexpr int tap = kstep >> 2, ks = kstep & 3, toff = (tap / 3) * HTX + (tap % 3);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int hr = hb[i] + toff;
-                    pf[buf][i] = lds_read_b128(lds_base + T1_OFF + hr * ROWB + ((ch ^ ((hr >> 1) & 7)) << 4));
+                    if (PAD) pf[buf][i] = lds_read_b128_o<toff * T1R + ks * 32>(rb[i]);
+                    else {
+                        const int hr = hb[i] + toff, ch = 2 * ks + lhalf;
+                        pf[buf][i] = lds_read_b128(lds_base + T1_OFF + hr * ROWB + ((ch ^ ((hr >> 1) & 7)) << 4));
+                    }
                 }
             };
-            rd(0, 0);
+            auto chunk = [&](auto cc, uint4 (&wcur)[3], uint4 (&wnext)[3]) {      // 3 k-steps; the next 3 fragments in flight
+                constexpr int C3 = decltype(cc)::value;
+                if (C3 < 5) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                if (j < 5) rd(j + 1, (j + 1) & 1);
-                if (j < 5) lgkm_wait<2>(); else lgkm_wait<0>();
-                acc[0] = mfma_bf16(wc[j], pf[j & 1][0], acc[0]);
-                acc[1] = mfma_bf16(wc[j], pf[j & 1][1], acc[1]);
-            }
-        }
+                    for (int j = 0; j < 3; ++j) wnext[j] = *wfrag(p.fb, ctw, 36, K0 + (C3 + 1) * 3 + j, lane);
+                }
+                auto step = [&](auto jc) {
+                    constexpr int J = decltype(jc)::value, KS = C3 * 3 + J;     // k-step of this half, 0..17
+                    if constexpr (KS < 17) rd(std::integral_constant<int, KS + 1>{}, (KS + 1) & 1);
+                    if (KS < 17) lgkm_wait<2>(); else lgkm_wait<0>();
+                    const u32x4 w = as_u32x4(wcur[J]);
+                    acc[0] = mfma_bf16(w, pf[KS & 1][0], acc[0]);
+                    acc[1] = mfma_bf16(w, pf[KS & 1][1], acc[1]);
+                };
+                step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            };
+            rd(std::integral_constant<int, 0>{}, 0);
+            chunk(std::integral_constant<int, 0>{}, wnb, wnb2);
+            chunk(std::integral_constant<int, 1>{}, wnb2, wnb);
+            chunk(std::integral_constant<int, 2>{}, wnb, wnb2);
+            chunk(std::integral_constant<int, 3>{}, wnb2, wnb);
+            chunk(std::integral_constant<int, 4>{}, wnb, wnb2);
+            chunk(std::integral_constant<int, 5>{}, wnb2, wnb);
+        };
+        if (kh) run_half(std::integral_constant<int, 1>{}); else run_half(std::integral_constant<int, 0>{});
         stamp(3);
         constexpr int KSC = DS ? 8 : 4;              // DS: [conv3 | downsample] concatenated along K, second half reads x
 #pragma unroll
@@ -953,9 +976,14 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
         auto pix = [&](int q) { return (size_t)((y0 + (q >> 4)) * HW + x0 + (q & 15)) * COUT; };
 
         const size_t cofs = (size_t)wave * 32 + 8 * u;
+        // element (pixel tile i, half it) of this lane = tile pixel i*32 + it*16 + prr = frame row y0 + 2i + it, column x0 + prr:
+        // one base pointer + a row pitch per step instead of a 64-bit index computation per access
+        constexpr size_t RPITCH = (size_t)HW * COUT;
+        const bf16_t* xrow = X + pix(prr) + cofs;
+        bf16_t* yrow = Y + pix(prr) + cofs;
         uint4 rr[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) rr[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
+        for (int it = 0; it < 2; ++it) rr[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(xrow + it * RPITCH);
         {
             float4 bq[4];
 #pragma unroll
@@ -1029,7 +1057,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
             uint4 rn[2];
             if (i < 3) {
 #pragma unroll
-                for (int it = 0; it < 2; ++it) rn[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(X + pix((i + 1) * 32 + it * 16 + prr) + cofs);
+                for (int it = 0; it < 2; ++it) rn[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(xrow + (2 * (i + 1) + it) * RPITCH);
             }
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -1042,7 +1070,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
-                *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *reinterpret_cast<uint4*>(yrow + (2 * i + it) * RPITCH) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
             if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
         }
