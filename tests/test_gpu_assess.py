@@ -192,6 +192,27 @@ def test_wide_1x1_conv_matches_tiled_kernel(dev, net16):
             np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
 
 
+def test_chained_res4_blocks_are_bit_identical_to_separate_launches(dev, net16):
+    """bf16 mode: res4's five identity blocks chained inside one launch (tunable STAGE_RUN=1, default; the workgroup that
+    wrote a frame is its only reader, workgroup-scope release / acquire between blocks) against one launch per block:
+    the same kernel body on the same data -> bit-identical stage output and scores, for a full and a ragged batch."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge in ((8, True), (3, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        try:
+            lib.ivosw_tune_set(b"STAGE_RUN", 1)
+            _, a = net16.forward_tap(ttf, ttp, "res4")
+            sa = net16(ttf, ttp).cpu().numpy()
+            lib.ivosw_tune_set(b"STAGE_RUN", 0)
+            _, b = net16.forward_tap(ttf, ttp, "res4")
+            sb = net16(ttf, ttp).cpu().numpy()
+        finally:
+            lib.ivosw_tune_set(b"STAGE_RUN", 1)
+        assert torch.equal(a, b)
+        np.testing.assert_array_equal(sa, sb)
+
+
 def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
     """bf16 mode: the 3x3 stride-1 layers with the halo patch LDS-resident (tunable PATCH3=1, default) against the
     per-tap implicit-GEMM kernel (PATCH3=0): same operands, same K order inside a tap, different accumulation order
