@@ -74,3 +74,29 @@ def test_objects_and_sequence_metric():
     one = jo.sequence_metric('J', g2, p2, 2, convert_to_single_obj=True)
     assert g2.max() == 1 and p2.max() == 1                                           # the reference rewrites its inputs
     np.testing.assert_array_equal(one, [(100 + 60) / (100 + 130)] * 2)
+
+
+def test_f_measure_against_brute_force_definition():
+    """An independent restatement of the matching step: a boundary pixel of A is matched when some boundary pixel of B lies
+    within Euclidean distance bound_pix (disk structuring element), checked pair by pair in pure Python on small random
+    masks — pins the dilation / disk convention of the oracle (scipy.ndimage) against the definition itself."""
+    rs = np.random.RandomState(0)
+    for trial in range(12):
+        H, W = rs.randint(6, 15), rs.randint(6, 15)
+        gt = (rs.rand(H, W) < 0.35)
+        pr = gt.copy()
+        flip = rs.rand(H, W) < 0.15
+        pr[flip] = ~pr[flip]
+        r = int(rs.randint(1, 4))
+        bg, bp = jo.seg2bmap(gt), jo.seg2bmap(pr)
+        pg, pp = np.argwhere(bg), np.argwhere(bp)
+
+        def matched(src, dst):
+            n = 0
+            for (y, x) in src:
+                if any((y - v) ** 2 + (x - u) ** 2 <= r * r for (v, u) in dst):
+                    n += 1
+            return n
+        want = jo.pr_to_f(len(pp), len(pg), matched(pp, pg), matched(pg, pp))
+        got = jo.f_measure(gt, pr, bound_th=r)
+        assert got == want, (trial, H, W, r)
