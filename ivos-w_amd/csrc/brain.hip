@@ -155,22 +155,23 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwd p) {
                 p.gates[(((size_t)d * Nk + (n - p.keep_from)) * p.T + t) * 512 + tid] = act;
         }
         __syncthreads();
-        if (tid < HD) {
-#pragma unroll 1
-            for (int r = 0; r < R; ++r) {
-                const int row = row0 + r;
-                if (row >= 2 * p.N) break;
+        {
+            // state update: 128 threads per row, the R rows side by side (they used to queue behind one another on the
+            // first two waves while the other six idled)
+            const int r = tid >> 7, j = tid & (HD - 1);
+            const int row = row0 + r;
+            if (r < R && row < 2 * p.N) {
                 const int d = row / p.N, n = row - d * p.N;
                 const int t = d ? p.T - 1 - s : s;
-                const float gi = g_s[r][tid], gf = g_s[r][HD + tid], gg = g_s[r][2 * HD + tid], go = g_s[r][3 * HD + tid];
+                const float gi = g_s[r][j], gf = g_s[r][HD + j], gg = g_s[r][2 * HD + j], go = g_s[r][3 * HD + j];
                 const bool keep = p.gates && n >= p.keep_from;
-                const size_t sidx = (((size_t)d * Nk + (n - p.keep_from)) * p.T + t) * HD + tid;
-                if (keep) p.hprev[sidx] = h_s[r][tid];
-                const float c = fmaf(gf, c_s[r][tid], gi * gg);
+                const size_t sidx = (((size_t)d * Nk + (n - p.keep_from)) * p.T + t) * HD + j;
+                if (keep) p.hprev[sidx] = h_s[r][j];
+                const float c = fmaf(gf, c_s[r][j], gi * gg);
                 const float h = go * tanhf_(c);
-                c_s[r][tid] = c;
-                h_s[r][tid] = h;
-                p.hs[((size_t)n * p.T + t) * 256 + d * HD + tid] = h;
+                c_s[r][j] = c;
+                h_s[r][j] = h;
+                p.hs[((size_t)n * p.T + t) * 256 + d * HD + j] = h;
                 if (keep) p.cs[sidx] = c;
             }
         }
