@@ -72,6 +72,13 @@ int ivosw_dqn_loss_grad(const float* policy, const float* target,
 int ivosw_clamp_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n,
                      int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                      float clamp, float grad_scale, ivosw_stream_t stream);
+/* The same update with Adam's step counter and bias corrections kept on the device (adam_state: ivosw_adam_state_bytes()
+ * bytes, zero-initialised = step 0; float64 running products of beta1 / beta2), so that a HIP graph that captured the call
+ * replays correctly: every call (or replay) advances the step by one.                                                 */
+size_t ivosw_adam_state_bytes(void);
+int ivosw_clamp_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, void* adam_state,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, float clamp,
+                         float grad_scale, ivosw_stream_t stream);
 /* Replaces target_net.load_state_dict(policy_net.state_dict()) (models/agent.py:163-165).        */
 int ivosw_copy_f32(float* dst, const float* src, size_t n, ivosw_stream_t stream);
 
@@ -114,6 +121,20 @@ size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk);
 int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp,
                          int B, int H, int W, float* scores, void* ws, size_t ws_bytes, int chunk,
                          int tap_stage, void* tap_out, ivosw_stream_t stream);
+/* The same forward for the O objects of ONE n-frame video without replicating the frames (recommend_frame scores one object
+ * at a time on the same all_F, utils/utils_agent.py:118-119): tf [n_frames,3,H,W]; unit u = obj * n_frames + frame reads
+ * frame u % n_frames and the mask plane at masks + obj * mask_stride_obj + frame * mask_stride_frame (strides in elements;
+ * for the reference's all_P [n,O+1,H,W]: masks = all_P + H*W, stride_frame = (O+1)*H*W, stride_obj = H*W).
+ * scores [n_obj * n_frames] fp32, object-major.  Workspace: ivosw_assess_ws_bytes with B = n_obj * n_frames.            */
+int ivosw_assess_forward_objects(const void* packed, int dtype, const float* tf, int n_frames, const float* masks,
+                                 long mask_stride_frame, long mask_stride_obj, int n_obj, int H, int W, float* scores,
+                                 void* ws, size_t ws_bytes, int chunk, ivosw_stream_t stream);
+/* Replaces `mask_quality[:] = pred.mean(1); state = np.stack([mask_quality, counts], 1)` (utils/utils_agent.py:120-121) on
+ * the device: scores [n_obj][n_frames] fp32 (as ivosw_assess_forward_objects writes them), counts [n_frames] fp32 ->
+ * quality [n_frames] float64 (numpy's float64 mean of the float32 predictions, same summation order) and
+ * state [n_frames,2] fp32 = (float32(quality), counts), the Brain's input.                                              */
+int ivosw_quality_state(const float* scores, int n_obj, int n_frames, const float* counts, double* quality,
+                        float* state, ivosw_stream_t stream);
 /* Kernel-name patterns of the dominant kernel family (the tower's contraction kernels) for profiling. */
 const char* ivosw_assess_dominant_kernel(int dtype);
 
@@ -146,6 +167,11 @@ int ivosw_seg_epilogue(const float* logits, int n, int C, int hs, int ws, int H,
  * the dominant kernel family (conv_igemm*, conv1x1_wide*, conv3x3_patch*, bneck*, stem_pool*) is bracketed by hipEvents on the launch stream; stop
  * synchronises those events and returns the summed kernel time (ms) and the launch count.          */
 int ivosw_profile_start(void);
+/* Span mode (what bench.py's `roofline` uses, inside the timed region): ONE event pair around each uninterrupted run of
+ * tower launches (stem .. the last res5 kernel of a pass; the ROI sampler and the pool+fc kernel are outside).  stop
+ * synchronises the events and returns the summed span time (ms), the number of spans and of family launches in them. */
+int ivosw_profile_span_start(void);
+int ivosw_profile_span_stop(double* total_ms, int* spans, int* launches);
 int ivosw_profile_stop(double* total_ms, int* launches);
 /* Text table (one line per distinct conv layer shape: calls, avg us, TFLOP/s, GB/s) of the launches recorded
  * since ivosw_profile_start; call before ivosw_profile_stop.  buf is a HOST buffer of `cap` bytes.       */

@@ -26,6 +26,8 @@ SIGNATURES = {
     "ivosw_dqn_ws_bytes": (_sz, [_i, _i]),
     "ivosw_dqn_loss_grad": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "ivosw_clamp_adam": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _f, _f, _f, _f, _f, _p]),
+    "ivosw_adam_state_bytes": (_sz, []),
+    "ivosw_clamp_adam_dev": (_i, [_p, _p, _p, _p, _i, _p, _f, _f, _f, _f, _f, _f, _f, _p]),
     "ivosw_copy_f32": (_i, [_p, _p, _sz, _p]),
     "ivosw_replay_gather": (_i, [_p] * 8 + [_i, _i] + [_p] * 5 + [_p]),
     "ivosw_mask_bbox": (_i, [_p, _i, _i, _i, _p, _p, _p]),
@@ -34,11 +36,15 @@ SIGNATURES = {
     "ivosw_assess_pack": (_i, [_p, _i, C.POINTER(_p), _i, _p]),
     "ivosw_assess_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ivosw_assess_forward": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _sz, _i, _i, _p, _p]),
+    "ivosw_assess_forward_objects": (_i, [_p, _i, _p, _i, _p, C.c_long, C.c_long, _i, _i, _i, _p, _p, _sz, _i, _p]),
+    "ivosw_quality_state": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "ivosw_assess_dominant_kernel": (C.c_char_p, [_i]),
     "ivosw_jf_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "ivosw_jf_counts": (_i, [_p, _p, _i, _i, _i, C.c_char_p, _i, _i, _p, _p, _sz, _p]),
     "ivosw_seg_epilogue": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, C.c_long, C.c_long, _p, _p, _p, _p]),
     "ivosw_profile_start": (_i, []),
+    "ivosw_profile_span_start": (_i, []),
+    "ivosw_profile_span_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i)]),
     "ivosw_profile_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "ivosw_profile_report": (_i, [C.c_char_p, _sz]),
     "ivosw_tune_set": (_i, [C.c_char_p, _i]),

@@ -150,6 +150,7 @@ extern "C" size_t ivosw_assess_packed_bytes(int dtype) {
 
 extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* tensors, int ntensors, ivosw_stream_t stream) {
     IVOSW_REQUIRE(packed && tensors, "null pointer");
+    IVOSW_ON_DEVICE_OF(packed);
     IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
     IVOSW_REQUIRE(ntensors == IVOSW_ASSESS_NTENSORS, "expected the 326 tensors of AssessNet.state_dict()");
     const Plan& P = plan_for(dtype);
@@ -203,10 +204,33 @@ extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
     return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
+static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,
+                               float* scores, void* ws, size_t ws_bytes, int chunk, int tap_stage, void* tap_out,
+                               ivosw_stream_t stream);
+
 extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp, int B, int H, int W,
                                     float* scores, void* ws, size_t ws_bytes, int chunk, int tap_stage, void* tap_out,
                                     ivosw_stream_t stream) {
+    return assess_forward_impl(packed, dtype, tf, tp, SampleMap{B, (long)H * W, 0}, B, H, W, scores, ws, ws_bytes, chunk, tap_stage,
+                               tap_out, stream);
+}
+
+extern "C" int ivosw_assess_forward_objects(const void* packed, int dtype, const float* tf, int n_frames, const float* masks,
+                                            long mask_stride_frame, long mask_stride_obj, int n_obj, int H, int W, float* scores,
+                                            void* ws, size_t ws_bytes, int chunk, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(n_frames > 0 && n_obj > 0, "n_frames and n_obj must be positive");
+    IVOSW_REQUIRE((long)n_frames * n_obj < (1L << 30), "too many (frame, object) units for one call");
+    IVOSW_REQUIRE(mask_stride_frame >= (long)H * W || n_frames == 1, "mask planes of consecutive frames overlap");
+    IVOSW_REQUIRE(mask_stride_obj >= 0 && mask_stride_frame >= 0, "negative mask stride");
+    return assess_forward_impl(packed, dtype, tf, masks, SampleMap{n_frames, mask_stride_frame, mask_stride_obj}, n_frames * n_obj, H,
+                               W, scores, ws, ws_bytes, chunk, 0, nullptr, stream);
+}
+
+static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,
+                               float* scores, void* ws, size_t ws_bytes, int chunk, int tap_stage, void* tap_out,
+                               ivosw_stream_t stream) {
     IVOSW_REQUIRE(packed && tf && tp && scores && ws, "null pointer");
+    IVOSW_ON_DEVICE_OF(scores);
     IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
     IVOSW_REQUIRE(tap_stage >= 0 && tap_stage <= 8, "tap_stage out of range");
@@ -215,7 +239,7 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
     if (chunk > B) chunk = B;
     IVOSW_REQUIRE(tap_stage == 0 || B <= chunk, "taps need B <= chunk");
     if (ws_bytes < ivosw_assess_ws_bytes(dtype, B, H, W, chunk)) {
-        set_error("ivosw_assess_forward: workspace %zu < %zu", ws_bytes, ivosw_assess_ws_bytes(dtype, B, H, W, chunk));
+        set_error("ivosw_assess_forward: workspace %zu < %zu", ws_bytes, ivosw_assess_ws_bytes(dtype, B, H, W, chunk));  // B = units
         return IVOSW_ERR_WS;
     }
     hipStream_t st = as_stream(stream);
@@ -230,11 +254,10 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
     };
 
     // K1/K2: mask -> (y,x,h,w) for the whole batch, on device
-    launch_mask_bbox(tp, B, H, W, bf.yxhw, bf.box, st);
+    launch_mask_bbox(tp, 0, B, H, W, sm, bf.yxhw, bf.box, st);
     // Encoder.mean/std come from the checkpoint: the sampler reads them from the packed arena
     RoiNorm nrm{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, reinterpret_cast<const float*>(base + P.norm_off)};
 
-    const size_t plane = (size_t)H * W;
     const int nblk[4] = {3, 4, 6, 3}, first_blk[4] = {0, 3, 7, 13}, hw_in[4] = {64, 64, 32, 16};
     const int cs[4] = {chunk, chunk * 2, chunk * 4, chunk * 8};
 
@@ -346,10 +369,11 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
                 for (int f0 = f1; f0 < f1 + n1; f0 += cs[0]) {
                     const int nb = std::min(cs[0], f1 + n1 - f0);
                     // K3: ROI crop-resize + normalise -> NHWC4
-                    launch_roi_sample(tf + (size_t)f0 * 3 * plane, tp + (size_t)f0 * plane, bf.yxhw + (size_t)f0 * 4, nb, H, W,
-                                      dtype, nrm, bf.roi, st);
+                    span_close(st);
+                    launch_roi_sample(tf, tp, bf.yxhw + (size_t)f0 * 4, f0, nb, H, W, dtype, sm, nrm, bf.roi, st);
                     tap(1, bf.roi, nb * E_ROI * es);
                     // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool (bf16: one fused kernel unless the stem tap is wanted)
+                    span_open(st);
                     if (dtype == IVOSW_BF16 && tap_stage != 2 && tune_get("FUSE_STEM", 1)) {
                         launch_stem_pool(bf.roi, base + P.stem_w_off, reinterpret_cast<const float*>(base + P.stem_b_off), nb, bf.pa, st);
                     } else {
@@ -377,6 +401,7 @@ extern "C" int ivosw_assess_forward(const void* packed, int dtype, const float* 
         run_stage(3, bf.in[2], n3, bf.pa);  // c0*8 frames x 131k elements == c0 * E_BIG: fits a ping-pong buffer
         tap(7, bf.pa, n3 * E_OUT[3] * es);
         // K6: 8x8 average pool + fc1
+        span_close(st);
         launch_pool_fc(bf.pa, n3, dtype, reinterpret_cast<const float*>(base + P.fcw_off),
                        reinterpret_cast<const float*>(base + P.fcb_off), scores + f3, tap_stage == 8 ? bf.pooled : nullptr, st);
         tap(8, bf.pooled, (size_t)n3 * 2048 * sizeof(float));

@@ -23,11 +23,12 @@ __global__ void bbox_init_kernel(int32_t* __restrict__ box, int B) {
 }
 
 // grid (S, B): block s scans elements [s*chunk, (s+1)*chunk) of sample b's flat H*W plane.
-__global__ __launch_bounds__(256) void bbox_scan_kernel(const float* __restrict__ tp, int H, int W, int chunk,
+__global__ __launch_bounds__(256) void bbox_scan_kernel(const float* __restrict__ tp, int b0, SampleMap sm, int H, int W, int chunk,
                                                         int vec_ok, int32_t* __restrict__ box) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.y;            // box / yxhw rows are local to the launch; the sample map uses the global index
     const size_t plane = (size_t)H * W;
-    const float* p = tp + (size_t)b * plane;
+    const int bg = b0 + b;
+    const float* p = tp + (size_t)(bg / sm.n_frames) * sm.stride_obj + (size_t)(bg % sm.n_frames) * sm.stride_frame;
     const size_t beg = (size_t)blockIdx.x * chunk;
     const size_t end = min(plane, beg + (size_t)chunk);
     int ymin = INT_MAX, ymax = -1, xmin = INT_MAX, xmax = -1;
@@ -90,15 +91,15 @@ __global__ void bbox_finalize_kernel(const int32_t* __restrict__ box, int B, int
     yxhw[b * 4 + 3] = (float)(fx1 - fx0 + 1.0);
 }
 
-void launch_mask_bbox(const float* tp, int B, int H, int W, float* yxhw, int32_t* scratch, hipStream_t st) {
+void launch_mask_bbox(const float* tp, int b0, int B, int H, int W, const SampleMap& sm, float* yxhw, int32_t* scratch, hipStream_t st) {
     hipLaunchKernelGGL(bbox_init_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scratch, B);
     const size_t plane = (size_t)H * W;
     int S = (int)max((size_t)1, min((size_t)64, (size_t)2048 / (size_t)B));
     size_t chunk = (plane + S - 1) / S;
     chunk = (chunk + 1023) / 1024 * 1024;  // multiple of 4 (and of the 1024-element block stride)
     S = (int)((plane + chunk - 1) / chunk);
-    const int vec_ok = (plane % 4 == 0) && ((reinterpret_cast<uintptr_t>(tp) & 15) == 0);
-    hipLaunchKernelGGL(bbox_scan_kernel, dim3(S, B), dim3(256), 0, st, tp, H, W, (int)chunk, vec_ok, scratch);
+    const int vec_ok = (plane % 4 == 0) && ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) && sm.stride_frame % 4 == 0 && sm.stride_obj % 4 == 0;
+    hipLaunchKernelGGL(bbox_scan_kernel, dim3(S, B), dim3(256), 0, st, tp, b0, sm, H, W, (int)chunk, vec_ok, scratch);
     hipLaunchKernelGGL(bbox_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, st, scratch, B, H, W, yxhw);
 }
 
@@ -111,9 +112,10 @@ __device__ __forceinline__ float lin_m1_1(int j, int n) {  // torch.linspace(-1,
 // grid (256 rows, B), block 256 (one output pixel per thread): roi[b][i][j][0..3] = (R,G,B normalised, P)
 template <typename T>
 __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict__ tf, const float* __restrict__ tp,
-                                                         const float* __restrict__ yxhw, int H, int W, RoiNorm nrm,
+                                                         const float* __restrict__ yxhw, int b0, SampleMap sm, int H, int W, RoiNorm nrm,
                                                          T* __restrict__ roi) {
-    const int b = blockIdx.y, i = blockIdx.x, j = threadIdx.x;
+    const int b = blockIdx.y, i = blockIdx.x, j = threadIdx.x;     // yxhw / roi rows are local to the launch
+    const int bg = b0 + b, fr = bg % sm.n_frames;
     const float ry = yxhw[b * 4 + 0], rx = yxhw[b * 4 + 1], rh = yxhw[b * 4 + 2], rw = yxhw[b * 4 + 3];
     // get_ROI_grid (assessment.py:79-92), fp32, same operation order as the reference.  NOTE: HIP's __fmul_rn / __fadd_rn
     // are plain operators inside header functions, so hipcc still contracts mul+add pairs into FMAs here (as the GEMM
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict
     float v[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float* src = (c < 3) ? tf + ((size_t)b * 3 + c) * plane : tp + (size_t)b * plane;
+        const float* src = (c < 3) ? tf + ((size_t)fr * 3 + c) * plane
+                                   : tp + (size_t)(bg / sm.n_frames) * sm.stride_obj + (size_t)fr * sm.stride_frame;
         v[c][0] = src[o00]; v[c][1] = src[o01]; v[c][2] = src[o10]; v[c][3] = src[o11];
     }
     float out[4];
@@ -173,13 +176,13 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict
     }
 }
 
-void launch_roi_sample(const float* tf, const float* tp, const float* yxhw, int B, int H, int W, int dtype,
-                       const RoiNorm& nrm, void* roi, hipStream_t st) {
+void launch_roi_sample(const float* tf, const float* tp, const float* yxhw, int b0, int B, int H, int W, int dtype,
+                       const SampleMap& sm, const RoiNorm& nrm, void* roi, hipStream_t st) {
     if (dtype == IVOSW_F32)
-        hipLaunchKernelGGL(roi_sample_kernel<float>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, H, W, nrm,
+        hipLaunchKernelGGL(roi_sample_kernel<float>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, b0, sm, H, W, nrm,
                            static_cast<float*>(roi));
     else
-        hipLaunchKernelGGL(roi_sample_kernel<bf16_t>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, H, W, nrm,
+        hipLaunchKernelGGL(roi_sample_kernel<bf16_t>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, b0, sm, H, W, nrm,
                            static_cast<bf16_t*>(roi));
 }
 
@@ -190,8 +193,9 @@ using namespace ivosw;
 extern "C" int ivosw_mask_bbox(const float* tp, int B, int H, int W, float* yxhw, int32_t* scratch,
                                ivosw_stream_t stream) {
     IVOSW_REQUIRE(tp && yxhw && scratch, "null pointer");
+    IVOSW_ON_DEVICE_OF(yxhw);
     IVOSW_REQUIRE(B > 0 && H > 0 && W > 0, "B, H, W must be positive");
-    launch_mask_bbox(tp, B, H, W, yxhw, scratch, as_stream(stream));
+    launch_mask_bbox(tp, 0, B, H, W, SampleMap{B, (long)H * W, 0}, yxhw, scratch, as_stream(stream));
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
@@ -199,10 +203,11 @@ extern "C" int ivosw_mask_bbox(const float* tp, int B, int H, int W, float* yxhw
 extern "C" int ivosw_roi_sample(const float* tf, const float* tp, const float* yxhw, int B, int H, int W, int dtype,
                                 void* roi, ivosw_stream_t stream) {
     IVOSW_REQUIRE(tf && tp && yxhw && roi, "null pointer");
+    IVOSW_ON_DEVICE_OF(roi);
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
     IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
     RoiNorm nrm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, nullptr};  // Encoder.mean/std (assessment.py:41-44)
-    launch_roi_sample(tf, tp, yxhw, B, H, W, dtype, nrm, roi, as_stream(stream));
+    launch_roi_sample(tf, tp, yxhw, 0, B, H, W, dtype, SampleMap{B, (long)H * W, 0}, nrm, roi, as_stream(stream));
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }

@@ -581,6 +581,7 @@ extern "C" int ivosw_bneck_probe(const void* x, void* y, const void* wa, const f
                                  unsigned long long* ts, ivosw_stream_t stream) {
     using namespace ivosw;
     IVOSW_REQUIRE(x && y && wa && ba && wb && bb && wc && bc && zeros, "null pointer");
+    IVOSW_ON_DEVICE_OF(y);
     BneckArgs a{};
     a.x = x; a.y = y; a.wa = wa; a.ba = ba; a.wb = wb; a.bb = bb; a.wc = wc; a.bc = bc; a.wd = wd; a.bd = bd; a.zeros = zeros;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cmid = Cmid; a.ts = ts;

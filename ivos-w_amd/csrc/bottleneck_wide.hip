@@ -1325,6 +1325,7 @@ extern "C" int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, co
                                       unsigned long long* ts, ivosw_stream_t stream) {
     using namespace ivosw;
     IVOSW_REQUIRE(x && y && wa && ba && wb && bb && wc && bc && frag, "null pointer");
+    IVOSW_ON_DEVICE_OF(y);
     hipStream_t st = as_stream(stream);
     char* f = static_cast<char*>(frag);
     const size_t n1 = (size_t)Cmid * Cin * 2, n2 = (size_t)Cmid * 9 * Cmid * 2;

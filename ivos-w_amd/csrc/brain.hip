@@ -8,6 +8,8 @@
 // walks the T steps with h broadcast from LDS: rows (sample x direction) map to workgroups, so a
 // 128-sample minibatch fills all 256 CUs.  fp32 throughout (exact fma chains); MFMA is used for the
 // dense batched contractions only (gemm_f32.h).
+#include <mutex>
+
 #include "gemm_f32.h"
 
 namespace ivosw {
@@ -421,22 +423,36 @@ int tune_get(const char* key, int dflt);   // capi.cpp
 
 static constexpr int WG_SPLIT = 16;
 
-// One helper stream + a few events per device, created on first use and kept for the life of the process.
+// One helper stream + four events per device: the only state the library keeps between calls (documented in
+// INTEGRATION.md).  Creation is serialised and all-or-nothing; ivosw_dqn_loss_grad holds the device's mutex while it
+// enqueues, so two host threads (or two caller streams) on one device cannot interleave their fork / join pairs — an
+// event re-recorded by a later call does not disturb waits that were already enqueued on it.
 struct Side {
+    std::mutex mu;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[4] = {};
+    bool tried = false;
 };
 static Side* side_for_current_device() {
-    static Side sides[16];
+    static Side sides[64];
+    static std::mutex init_mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     Side& s = sides[dev];
-    if (!s.stream) {
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
-        for (auto& e : s.ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!s.tried) {
+        s.tried = true;
+        bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+        int made = 0;
+        for (; ok && made < 4; ++made) ok = hipEventCreateWithFlags(&s.ev[made], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {      // partial failure: give everything back, the single-stream path is used from now on
+            for (int i = 0; i < made; ++i) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            s.stream = nullptr;
+            (void)hipGetLastError();
+        }
     }
-    return &s;
+    return s.stream ? &s : nullptr;
 }
 
 static size_t dqn_ws_floats(int B, int T) {
@@ -461,6 +477,7 @@ extern "C" size_t ivosw_brain_ws_bytes(int N, int T) {
 extern "C" int ivosw_brain_forward(const float* params, const float* x, int N, int T, float* q, void* ws,
                                    size_t ws_bytes, ivosw_stream_t stream) {
     IVOSW_REQUIRE(params && x && q && ws, "null pointer");
+    IVOSW_ON_DEVICE_OF(q);
     IVOSW_REQUIRE(N > 0 && T > 0, "N and T must be positive");
     if (ws_bytes < ivosw_brain_ws_bytes(N, T)) {
         set_error("ivosw_brain_forward: workspace %zu < %zu", ws_bytes, ivosw_brain_ws_bytes(N, T));
@@ -488,6 +505,7 @@ __global__ void argmax_rows_kernel(const float* __restrict__ q, int N, int T, in
 
 extern "C" int ivosw_brain_argmax(const float* q, int N, int T, int64_t* idx, ivosw_stream_t stream) {
     IVOSW_REQUIRE(q && idx, "null pointer");
+    IVOSW_ON_DEVICE_OF(idx);
     IVOSW_REQUIRE(N > 0 && T > 0, "N and T must be positive");
     hipLaunchKernelGGL(argmax_rows_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), q, N, T, idx);
     IVOSW_CHECK_LAUNCH();
@@ -505,6 +523,7 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
                                    void* ws, size_t ws_bytes, ivosw_stream_t stream) {
     IVOSW_REQUIRE(policy && target && state && new_state && action && reward_step && reward_done && grads && loss && ws,
                   "null pointer");
+    IVOSW_ON_DEVICE_OF(grads);
     IVOSW_REQUIRE(B > 0 && T > 0, "B and T must be positive");
     if (ws_bytes < ivosw_dqn_ws_bytes(B, T)) {
         set_error("ivosw_dqn_loss_grad: workspace %zu < %zu", ws_bytes, ivosw_dqn_ws_bytes(B, T));
@@ -532,16 +551,19 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     // The step is a chain of ~40 launches that each occupy a fraction of the chip for 5-30 us: independent branches run
     // on a second stream (fork / join with events), so their kernels overlap instead of queueing behind each other.
     Side* sd = tune_get("DQN_STREAMS", 1) ? side_for_current_device() : nullptr;
+    std::unique_lock<std::mutex> side_lock;
+    if (sd) side_lock = std::unique_lock<std::mutex>(sd->mu);
     hipStream_t s2 = sd ? sd->stream : st;
+    bool sync_ok = true;
     auto fork = [&](int k) {          // s2 continues after everything enqueued on st so far
         if (!sd) return;
-        (void)hipEventRecord(sd->ev[k], st);
-        (void)hipStreamWaitEvent(s2, sd->ev[k], 0);
+        sync_ok &= hipEventRecord(sd->ev[k], st) == hipSuccess;
+        sync_ok &= hipStreamWaitEvent(s2, sd->ev[k], 0) == hipSuccess;
     };
     auto join = [&](int k) {          // st continues after everything enqueued on s2 so far
         if (!sd) return;
-        (void)hipEventRecord(sd->ev[k], s2);
-        (void)hipStreamWaitEvent(st, sd->ev[k], 0);
+        sync_ok &= hipEventRecord(sd->ev[k], s2) == hipSuccess;
+        sync_ok &= hipStreamWaitEvent(st, sd->ev[k], 0) == hipSuccess;
     };
 
     // ---- forward: policy on [s'; s] in one batch, target on s' (agent.py:135-137,144); the target pass runs beside it
@@ -631,6 +653,11 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     launch_gemm_f32_splitk(g, grads + O_W1, w.slabs, WG_SPLIT, st);
     hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.da1, rows, 128, 128, grads + O_B1);
     join(3);
+    if (!sync_ok) {
+        (void)hipGetLastError();
+        set_error("ivosw_dqn_loss_grad: a fork/join event between the two streams failed");
+        return IVOSW_ERR_LAUNCH;
+    }
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }

@@ -13,6 +13,23 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+DeviceScope::DeviceScope(const void* p) {
+    hipPointerAttribute_t at{};
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();   // not a HIP allocation: clear the sticky error, the caller reports IVOSW_ERR_ARG
+        return;
+    }
+    if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) return;
+    dev = at.device;
+    if (hipGetDevice(&prev) != hipSuccess) return;
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) return;
+    ok = true;
+}
+
+DeviceScope::~DeviceScope() {
+    if (ok && prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+}
 }  // namespace ivosw
 
 namespace ivosw {

@@ -30,6 +30,27 @@ inline hipStream_t as_stream(ivosw_stream_t s) { return reinterpret_cast<hipStre
         }                                                                           \
     } while (0)
 
+// Every entry point runs on the device that OWNS its buffers, whatever the caller's current device is (the reference
+// builds torch.device(f'cuda:{gpu_id}') and never calls set_device, eval_agent_manet.py:63): the scope looks the device up
+// from a device pointer, switches to it for the duration of the call and restores the caller's device afterwards.
+struct DeviceScope {
+    int prev = -1, dev = -1;
+    bool ok = false;
+    explicit DeviceScope(const void* device_ptr);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+#define IVOSW_ON_DEVICE_OF(ptr)                                                                    \
+    ::ivosw::DeviceScope dscope__(ptr);                                                            \
+    do {                                                                                           \
+        if (!dscope__.ok) {                                                                        \
+            ::ivosw::set_error("%s: %s is not a device pointer (no CPU fallback)", __func__, #ptr); \
+            return IVOSW_ERR_ARG;                                                                  \
+        }                                                                                          \
+    } while (0)
+
 constexpr int WAVE = 64;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

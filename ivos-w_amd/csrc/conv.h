@@ -40,6 +40,8 @@ struct BneckArgs {
 };
 void* prof_begin(const ConvArgs& a, int es, hipStream_t st);   // measurement hook (ivosw_profile_*), see conv.hip
 void prof_end(void* tok, hipStream_t st);
+void span_open(hipStream_t st);    // span mode: start / end of an uninterrupted run of tower launches (assess.hip)
+void span_close(hipStream_t st);
 bool bneck_fusable(const BneckArgs& a);
 void launch_bneck(const BneckArgs& a, hipStream_t st);
 

@@ -880,12 +880,38 @@ struct ConvProfiler {
     std::vector<ConvArgs> args;
     std::vector<int> es;
     size_t used = 0;
+    // span mode (ivosw_profile_span_*): ONE event pair around each uninterrupted run of tower launches (stem .. last res5
+    // kernel of a pass), so the family time contains its own launch gaps but no per-launch event overhead, and
+    // family time <= wall time of the step holds by construction
+    bool span_on = false, span_is_open = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> sev;
+    size_t sused = 0;
+    long span_launches = 0;
 };
 static ConvProfiler g_prof;
+
+void span_open(hipStream_t st) {
+    if (!g_prof.span_on || g_prof.span_is_open) return;
+    if (g_prof.sused == g_prof.sev.size()) {
+        hipEvent_t x, y;
+        (void)hipEventCreate(&x);
+        (void)hipEventCreate(&y);
+        g_prof.sev.emplace_back(x, y);
+    }
+    (void)hipEventRecord(g_prof.sev[g_prof.sused].first, st);
+    g_prof.span_is_open = true;
+}
+void span_close(hipStream_t st) {
+    if (!g_prof.span_on || !g_prof.span_is_open) return;
+    (void)hipEventRecord(g_prof.sev[g_prof.sused].second, st);
+    ++g_prof.sused;
+    g_prof.span_is_open = false;
+}
 
 // begin/end of one profiled launch: `a` describes the layer for the report (KH == 0 marks a fused bottleneck:
 // Cin -> Cout/4 -> Cout/4 (3x3) -> Cout + residual)
 void* prof_begin(const ConvArgs& a, int es, hipStream_t st) {
+    if (g_prof.span_on && g_prof.span_is_open) ++g_prof.span_launches;
     if (!g_prof.on) return nullptr;
     if (g_prof.used == g_prof.ev.size()) {
         hipEvent_t x, y;
@@ -1106,6 +1132,32 @@ void launch_pool_fc(const void* x, int B, int dtype, const float* fcw, const flo
 }
 
 }  // namespace ivosw
+
+extern "C" int ivosw_profile_span_start(void) {
+    ivosw::g_prof.span_on = true;
+    ivosw::g_prof.span_is_open = false;
+    ivosw::g_prof.sused = 0;
+    ivosw::g_prof.span_launches = 0;
+    return IVOSW_OK;
+}
+
+extern "C" int ivosw_profile_span_stop(double* total_ms, int* spans, int* launches) {
+    using namespace ivosw;
+    IVOSW_REQUIRE(total_ms && spans && launches, "null pointer");
+    double tot = 0.0;
+    for (size_t i = 0; i < g_prof.sused; ++i) {
+        (void)hipEventSynchronize(g_prof.sev[i].second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.sev[i].first, g_prof.sev[i].second) == hipSuccess) tot += ms;
+    }
+    *total_ms = tot;
+    *spans = (int)g_prof.sused;
+    *launches = (int)g_prof.span_launches;
+    g_prof.span_on = false;
+    g_prof.span_is_open = false;
+    g_prof.sused = 0;
+    return IVOSW_OK;
+}
 
 extern "C" int ivosw_profile_start(void) {
     ivosw::g_prof.on = true;

@@ -49,14 +49,107 @@ __global__ void replay_gather_kernel(const float* __restrict__ old_iou, const fl
     }
 }
 
+// mask_quality[:] = pred.mean(1); state = stack([mask_quality, counts], 1) (utils/utils_agent.py:120-121) without leaving the
+// device.  pred is a float64 [n_frames, n_obj] array filled with the float32 scores, so the mean is a float64 sum in numpy's
+// order (add.reduce along the contiguous axis: sequential below 8 elements, else 8 interleaved partial sums combined
+// pairwise plus a sequential tail) divided by n_obj; the Brain then sees float32(mean) (torch.Tensor(state), agent.py:176).
+__global__ void quality_state_kernel(const float* __restrict__ scores, int n_obj, int n_frames, const float* __restrict__ counts,
+                                     double* __restrict__ quality, float* __restrict__ state) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    auto at = [&](int o) { return (double)scores[(size_t)o * n_frames + f]; };
+    double sum;
+    if (n_obj < 8) {
+        sum = at(0);        // numpy's reduce starts from the first element (no 0.0 + x)
+        for (int o = 1; o < n_obj; ++o) sum += at(o);
+    } else {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = at(j);
+        int i = 8;
+        for (; i + 8 <= n_obj; i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += at(i + j);
+        sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n_obj; ++i) sum += at(i);
+    }
+    const double q = sum / (double)n_obj;
+    quality[f] = q;
+    state[2 * f] = (float)q;
+    state[2 * f + 1] = counts[f];
+}
+
+// Adam's step counter and bias corrections kept ON the device, so that a captured HIP graph of the DQN step replays
+// correctly: tick advances {step, beta1^t, beta2^t} (float64 running products) and publishes step_size / sqrt(bc2).
+struct AdamDevState {
+    double b1t, b2t;
+    int step;
+    float step_size, bc2_sqrt;
+};
+__global__ void adam_tick_kernel(AdamDevState* st, float lr, float beta1, float beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    AdamDevState s = *st;
+    if (s.step == 0) { s.b1t = 1.0; s.b2t = 1.0; }
+    s.step += 1;
+    s.b1t *= (double)beta1;
+    s.b2t *= (double)beta2;
+    s.step_size = (float)((double)lr / (1.0 - s.b1t));
+    s.bc2_sqrt = (float)sqrt(1.0 - s.b2t);
+    *st = s;
+}
+__global__ void clamp_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                      float* __restrict__ v, int n, const AdamDevState* __restrict__ st, float beta1, float beta2,
+                                      float eps, float wd, float clampv, float gscale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float step_size = st->step_size, bc2_sqrt = st->bc2_sqrt;
+    float gi = g[i] * gscale;
+    gi = fminf(fmaxf(gi, -clampv), clampv);
+    const float pi = p[i];
+    gi = fmaf(wd, pi, gi);
+    float mi = m[i], vi = v[i];
+    mi = fmaf(gi - mi, 1.0f - beta1, mi);
+    vi = fmaf(1.0f - beta2, gi * gi, vi * beta2);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+}
+
 }  // namespace ivosw
 
 using namespace ivosw;
+
+extern "C" size_t ivosw_adam_state_bytes(void) { return sizeof(AdamDevState); }
+
+extern "C" int ivosw_clamp_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, void* adam_state,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, float clamp,
+                                    float grad_scale, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(params && grads && exp_avg && exp_avg_sq && adam_state, "null pointer");
+    IVOSW_ON_DEVICE_OF(params);
+    IVOSW_REQUIRE(n > 0, "n must be positive");
+    AdamDevState* sd = static_cast<AdamDevState*>(adam_state);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, as_stream(stream), sd, lr, beta1, beta2);
+    hipLaunchKernelGGL(clamp_adam_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), params, grads, exp_avg,
+                       exp_avg_sq, n, sd, beta1, beta2, eps, weight_decay, clamp, grad_scale);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+extern "C" int ivosw_quality_state(const float* scores, int n_obj, int n_frames, const float* counts, double* quality,
+                                   float* state, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(scores && counts && quality && state, "null pointer");
+    IVOSW_ON_DEVICE_OF(state);
+    IVOSW_REQUIRE(n_obj > 0 && n_frames > 0, "n_obj and n_frames must be positive");
+    hipLaunchKernelGGL(quality_state_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, as_stream(stream), scores, n_obj, n_frames,
+                       counts, quality, state);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
 
 extern "C" int ivosw_clamp_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, int step,
                                 float lr, float beta1, float beta2, float eps, float weight_decay, float clamp,
                                 float grad_scale, ivosw_stream_t stream) {
     IVOSW_REQUIRE(params && grads && exp_avg && exp_avg_sq, "null pointer");
+    IVOSW_ON_DEVICE_OF(params);
     IVOSW_REQUIRE(n > 0 && step >= 1, "n must be positive and step >= 1");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -70,6 +163,7 @@ extern "C" int ivosw_clamp_adam(float* params, const float* grads, float* exp_av
 
 extern "C" int ivosw_copy_f32(float* dst, const float* src, size_t n, ivosw_stream_t stream) {
     IVOSW_REQUIRE(dst && src, "null pointer");
+    IVOSW_ON_DEVICE_OF(dst);
     if (n == 0) return IVOSW_OK;
     hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream));
     if (e != hipSuccess) {
@@ -87,6 +181,7 @@ extern "C" int ivosw_replay_gather(const float* old_iou, const float* new_iou, c
     IVOSW_REQUIRE(old_iou && new_iou && annotated && next_annotated && action && reward_step && reward_done && idx,
                   "null input pointer");
     IVOSW_REQUIRE(state && new_state && action_out && reward_step_out && reward_done_out, "null output pointer");
+    IVOSW_ON_DEVICE_OF(state);
     IVOSW_REQUIRE(B > 0 && T > 0, "B and T must be positive");
     hipLaunchKernelGGL(replay_gather_kernel, dim3(B), dim3(64), 0, as_stream(stream), old_iou, new_iou, annotated,
                        next_annotated, action, reward_step, reward_done, idx, B, T, state, new_state, action_out,

@@ -234,6 +234,7 @@ extern "C" int ivosw_jf_counts(const uint8_t* gt, const uint8_t* pred, int N, in
                                ivosw_stream_t stream) {
     using namespace ivosw;
     IVOSW_REQUIRE(gt && pred && obj_ids && counts && ws, "null pointer");
+    IVOSW_ON_DEVICE_OF(counts);
     IVOSW_REQUIRE(N > 0 && H > 0 && W > 0, "N, H, W must be positive");
     IVOSW_REQUIRE(n_obj > 0 && n_obj <= JF_MAX_OBJ, "1..32 object ids");
     IVOSW_REQUIRE((long)N * n_obj <= 65535, "N * n_obj must fit one grid dimension (65535): split the sequence");

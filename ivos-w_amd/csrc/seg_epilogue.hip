@@ -142,6 +142,7 @@ extern "C" int ivosw_seg_epilogue(const float* logits, int n, int C, int hs, int
                                   float* label_f32, ivosw_stream_t stream) {
     using namespace ivosw;
     IVOSW_REQUIRE(logits, "null logits");
+    IVOSW_ON_DEVICE_OF(logits);
     IVOSW_REQUIRE(probs || label_i64 || label_u8 || label_f32, "no output requested");
     IVOSW_REQUIRE(n > 0 && n <= 65535 && C > 0 && hs > 0 && ws > 0 && H > 0 && W > 0, "bad shape");
     IVOSW_REQUIRE((long)H * W < (1L << 31) && (long)C * hs * ws < (1L << 31), "frame too large for 32-bit pixel indices");

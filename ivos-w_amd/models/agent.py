@@ -221,14 +221,19 @@ class Agent(nn.Module):
                                        L.stream_ptr(pn.flat.device)), "copy_f32")
 
     # ------------------------------------------------------------------ acting
-    def action(self, state, verbose=True):
+    def action(self, state, verbose=True, device_out=None):
+        """Reference surface: action(state [T,2] numpy, verbose) -> frame index (agent.py:168-196).  Extensions used by
+        utils_agent's device-resident chain: `state` may be a [T,2] fp32 CUDA tensor, and with `device_out` (int64 [1] on
+        the device) the greedy index is left THERE and None is returned, so the caller can fetch it together with its
+        other results in one D2H copy (the epsilon branch still returns a host integer)."""
         self.steps_done += 1
         if self.cfg.phase != "train":
             eps_threshold = 0
         else:
             eps_threshold = self.EPS_END + (self.EPS_START - self.EPS_END) * \
                 math.exp(-0.5 * self.steps_done / self.EPS_DECAY)
-        n_frames = np.asarray(state).shape[0]
+        on_device = torch.is_tensor(state) and state.is_cuda       # [T,2] fp32 already on the GPU (utils_agent's device chain)
+        n_frames = state.shape[0] if on_device else np.asarray(state).shape[0]
         rand_flag = random.random()
         greedy = rand_flag > eps_threshold
         if verbose:
@@ -236,11 +241,18 @@ class Agent(nn.Module):
                   f"frame index was selected {'by agent' if greedy else 'randomly'}")
         if not greedy:
             return random.choice(np.array(range(n_frames)))
-        x = torch.as_tensor(np.asarray(state)[np.newaxis], dtype=torch.float32).to(self.device)
-        q = self.policy_net(x)
-        idx = torch.empty(1, dtype=torch.int64, device=q.device)
+        st = state if on_device else torch.as_tensor(np.asarray(state), dtype=torch.float32).to(self.device)
+        if device_out is not None:
+            self.greedy_index_device(st, out=device_out)
+            return None
+        return np.int64(self.greedy_index_device(st).item())
+
+    def greedy_index_device(self, state, out=None):
+        """argmax_t Q(state)[t] for a device state [T,2] fp32, result left on the device (int64 [1], or written to `out`)."""
+        q = self.policy_net(state[None])
+        idx = out if out is not None else torch.empty(1, dtype=torch.int64, device=q.device)
         L.check(L.lib().ivosw_brain_argmax(L.dptr(q), 1, q.shape[1], L.dptr(idx), L.stream_ptr(q.device)), "argmax")
-        return np.int64(idx.item())
+        return idx
 
     # ------------------------------------------------------------------ bookkeeping
     def _update_avg_loss(self, loss):

@@ -94,12 +94,30 @@ class AssessNet(nn.Module):
         self.chunk = chunk
         self._packed = None
         self._packed_key = None
+        self._wver = 0                      # bumped whenever the weights can have changed (load_state_dict, .to(), ...)
         self._ws = L.Workspace()
 
     # ------------------------------------------------------------------ weights
+    def invalidate_packed(self):
+        """Call after modifying parameters in place by hand (load_state_dict / .to() / .float() do it themselves)."""
+        self._wver += 1
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self._wver += 1
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._wver += 1
+        return out
+
     def _weights_key(self):
-        return (self.precision, str(self.fc1.weight.device),
-                tuple((t.data_ptr(), t._version) for t in self.state_dict().values()))
+        # O(1): a forward at eval sizes (B ~ 100 frames) is ~1.6 ms of GPU time, walking the 326 tensors of the
+        # state_dict on every call cost a comparable amount of host time.  The first and last tensors stand guard
+        # against in-place edits that bypass the counter.
+        w0, w1 = self.Encoder.conv1.weight, self.fc1.weight
+        return (self.precision, self._wver, str(w1.device), w0.data_ptr(), w0._version, w1.data_ptr(), w1._version)
 
     def _ensure_packed(self):
         key = self._weights_key()
@@ -154,6 +172,31 @@ class AssessNet(nn.Module):
         reference's ``.squeeze()``, models/assessment.py:179)."""
         scores, _ = self._run(tf, tp)
         return scores if scores.shape[0] == 1 else scores[:, None]
+
+    def forward_objects(self, all_F, all_P, n_objects):
+        """Scores of every (object, frame) unit of ONE video without replicating the frames: all_F [n,3,H,W] fp32 on the
+        device, all_P [n,C,H,W] fp32 on the device (any layout whose [H,W] planes are contiguous, e.g. the object-major
+        ProbStore view), channel i+1 = object i (utils/utils_agent.py:118-119).  Returns [n_objects, n] fp32 on the device."""
+        if self.training:
+            raise RuntimeError("AssessNet on the MI355X path is inference-only; call .eval()")
+        n, C3, H, W = all_F.shape
+        assert C3 == 3 and all_P.shape[0] == n and tuple(all_P.shape[2:]) == (H, W) and all_P.shape[1] > n_objects
+        if all_F.dtype != torch.float32 or not all_F.is_contiguous():
+            all_F = all_F.detach().to(torch.float32).contiguous()
+        if all_P.dtype != torch.float32 or all_P.stride(3) != 1 or all_P.stride(2) != W:
+            all_P = all_P.detach().to(torch.float32).contiguous()
+        dev = all_F.device
+        packed = self._ensure_packed()
+        lib, dt = L.lib(), _DTYPES[self.precision]
+        units = n * n_objects
+        nbytes = lib.ivosw_assess_ws_bytes(dt, units, H, W, self.chunk)
+        ws = self._ws.get(nbytes, dev)
+        scores = torch.empty(n_objects, n, dtype=torch.float32, device=dev)
+        masks = all_P[:, 1:]                                # a view: channel 0 is the background
+        L.check(lib.ivosw_assess_forward_objects(L.dptr(packed), dt, L.dptr(all_F), n, ctypes.c_void_p(masks.data_ptr()),
+                                                 all_P.stride(0), all_P.stride(1), n_objects, H, W, L.dptr(scores),
+                                                 L.dptr(ws), nbytes, self.chunk, L.stream_ptr(dev)), "assess_forward_objects")
+        return scores
 
     def forward_tap(self, tf, tp, tap):
         """Debug/test hook: also returns one intermediate (NHWC; see ``_TAPS``)."""

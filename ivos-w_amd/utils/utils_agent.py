@@ -3,9 +3,10 @@
 Function names, argument meaning and return values follow /root/reference/utils/utils_agent.py
 (``goal_only_reward`` :7-35, ``select_next_frame`` :38-74, ``recommend_frame`` :77-128, ``gen_subseq`` :131-157,
 ``agent_train_data_collection`` :160-204, ``agent_business`` :207-256).  What changed is where the data lives:
-in the wild/ours and wild/worst branches the whole video stays on the GPU, all objects of a sequence are scored by
-ONE batched AssessNet launch (the reference runs one forward per object and copies the video H2D every
-interaction, :114-119), and the scores come back as one small D2H copy.
+in the wild/ours and wild/worst branches the video is uploaded ONCE per sequence and cached on the GPU, all objects of a
+sequence are scored by one batched AssessNet pass that reads every object's mask in place and shares one copy of the frames
+(the reference runs one forward per object and copies the video H2D every interaction, :114-119), and mask quality ->
+state -> Brain -> argmax runs on the device; one small D2H copy returns the quality vector and the recommended index.
 """
 import copy
 
@@ -76,16 +77,76 @@ def _annotation_counts(n, annotated_frames_list):
     return counts
 
 
+class _FrameCache:
+    """The video of the current sequence, resident on the GPU across interactions.  The reference uploads all_F (and all_P)
+    on EVERY interaction (utils/utils_agent.py:114-115: 100 frames x 480p fp32 = 0.5 GB, ~10 ms of PCIe per call); the entry
+    scripts build all_F once per sequence (eval_agent_manet.py:297-300), so its identity is a sound cache key."""
+
+    def __init__(self):
+        self.key, self.frames, self.uploads, self.hits = None, None, 0, 0
+
+    def get(self, all_F, device):
+        device = torch.device(device)
+        if all_F.is_cuda:
+            return all_F if all_F.device == device else all_F.to(device)
+        key = (all_F.data_ptr(), tuple(all_F.shape), all_F.dtype, all_F._version, str(device))
+        if key != self.key:
+            self.frames = all_F.to(device=device, dtype=torch.float32).contiguous()
+            self.key = key
+            self.uploads += 1
+        else:
+            self.hits += 1
+        return self.frames
+
+    def clear(self):
+        self.key, self.frames = None, None
+
+
+frame_cache = _FrameCache()
+
+
+def clear_frame_cache():
+    """Drop the cached video (call when a host all_F buffer is rewritten in place through numpy, which does not bump the
+    tensor version the cache key watches)."""
+    frame_cache.clear()
+
+
+def assess_all_objects_device(assess_net, all_F, all_P, n_objects, device):
+    """[n_objects, n_frame] quality predictions ON the device from one launch sequence: every object's masks are read in
+    place from all_P (channel i+1 = object i) and all objects share one device copy of the frames (frame-index
+    indirection inside ivosw_assess_forward_objects) - nothing is repeated, transposed or copied."""
+    frames = frame_cache.get(all_F, device)
+    probs = all_P if (all_P.is_cuda and all_P.device == torch.device(device)) else all_P.to(device)
+    return assess_net.forward_objects(frames, probs, n_objects)
+
+
 def assess_all_objects(assess_net, all_F, all_P, n_objects, device):
-    """[n_frame, n_objects] quality predictions from one batched launch: frames are repeated per object on the
-    device (the assessment kernels only read them) and channel i+1 of all_P is object i's soft mask."""
-    all_F = all_F.to(device)
-    all_P = all_P.to(device)
-    n = all_F.shape[0]
-    frames = all_F.repeat(n_objects, 1, 1, 1) if n_objects > 1 else all_F
-    masks = all_P[:, 1:n_objects + 1].transpose(0, 1).reshape(n_objects * n, *all_P.shape[2:]).contiguous()
-    scores = assess_net(frames, masks).reshape(n_objects, n)
-    return scores.transpose(0, 1).cpu().numpy()
+    """[n_frame, n_objects] quality predictions as a host array (one small D2H copy)."""
+    return assess_all_objects_device(assess_net, all_F, all_P, n_objects, device).transpose(0, 1).cpu().numpy()
+
+
+def _wild_assess(method, assess_net, agent, device, n_objects, all_F, all_P, counts, mask_quality, prev_frames):
+    """wild/worst and wild/ours (utils/utils_agent.py:111-122) with the chain quality -> state -> Brain -> argmax on the
+    device: per-object scores are averaged into mask_quality (float64, numpy's summation order) and stacked with the
+    annotation counts by ivosw_quality_state, the Brain and its first-max argmax read that state in place, and ONE D2H copy
+    brings back the n quality values the caller's array wants plus the recommended index."""
+    from .. import _lib as L
+    scores = assess_all_objects_device(assess_net, all_F, all_P, n_objects, device)
+    n = scores.shape[1]
+    dev = scores.device
+    out = torch.empty(n + 1, dtype=torch.float64, device=dev)          # [quality (n) | recommended index (int64 bits)]
+    state = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    cnt = torch.as_tensor(np.asarray(counts, dtype=np.float32)).to(dev, non_blocking=True)
+    L.check(L.lib().ivosw_quality_state(L.dptr(scores), n_objects, n, L.dptr(cnt), L.dptr(out), L.dptr(state),
+                                        L.stream_ptr(dev)), "quality_state")
+    idx_dev = out[n:].view(torch.int64)
+    idx_dev.zero_()
+    picked = agent.action(state, device_out=idx_dev) if method == "ours" else None
+    host = out.cpu()                                                    # the one D2H copy of the interaction
+    mask_quality[:] = host[:n].numpy()          # in place: the caller logs corr/diff from this array
+    if method == "worst":
+        return select_next_frame(mask_quality, metric="worst", prev_frames=prev_frames)
+    return picked if picked is not None else np.int64(host[n:].view(torch.int64)[0].item())
 
 
 def recommend_frame(cfg_yl, assess_net, agent, device, n_frame, n_objects, all_F, all_P, new_masks_quality, prev_frames,
@@ -106,14 +167,10 @@ def recommend_frame(cfg_yl, assess_net, agent, device, n_frame, n_objects, all_F
             subseq = gen_subseq(first_frame, n_frame, min(max_nb_interactions, n_frame), "equal")
             return next((i for i in subseq if i not in prev_frames), prev_frames[0])
         if method in ("worst", "ours"):
+            counts = _annotation_counts(len(new_masks_quality), annotated_frames_list)
             with torch.no_grad():
-                pred = assess_all_objects(assess_net, all_F, all_P, n_objects, device)
-            mask_quality[:] = pred.mean(1)          # in place: the caller logs corr/diff from this array
-            if method == "worst":
-                return select_next_frame(mask_quality, metric="worst", prev_frames=prev_frames)
-            state = np.stack([mask_quality, _annotation_counts(len(new_masks_quality), annotated_frames_list)], 1)
-            with torch.no_grad():
-                return agent.action(state)
+                return _wild_assess(method, assess_net, agent, device, n_objects, all_F, all_P, counts, mask_quality,
+                                    prev_frames)
         raise NotImplementedError
     raise NotImplementedError
 

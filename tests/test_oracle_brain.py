@@ -100,3 +100,30 @@ def test_three_update_steps_match_reference(gold, B):
 def test_epsilon_schedule():
     assert abs(bo.epsilon(0, 0.7, 0.25, 500) - 0.7) < 1e-12
     assert abs(bo.epsilon(1000, 0.7, 0.25, 500) - (0.25 + 0.45 * np.exp(-1.0))) < 1e-12
+
+
+@pytest.mark.parametrize("B", [32])
+def test_torch_cpu_baseline_matches_reference_golden(gold, B):
+    """bench.py's DQN cpu_baseline (stock torch-CPU ops, own module definitions) against the imported reference's goldens:
+    forward Q-values / argmax and three update steps (loss, parameter deltas, sync decisions)."""
+    from oracle.torch_cpu_baseline import TorchBrain, TorchDQN
+    gf, g = gold
+    net = TorchBrain()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.brain_state_dict(0).items()})
+    x = synth.brain_inputs(1, 37, 101)
+    with torch.no_grad():
+        q = net(torch.Tensor(x)).numpy()
+    np.testing.assert_allclose(q, gf["q_1_37"], rtol=1e-5, atol=1e-7)
+    assert np.array_equal(q.argmax(1), gf["argmax_1_37"])
+    tr = synth.replay_transitions(n=2000, T=25, seed=2019)
+    dqn = TorchDQN(synth.brain_state_dict(0), synth.brain_state_dict(1), CFG["gamma"], CFG["lr"], CFG["weight_decay"], CFG["update_rate"])
+    for step in range(3):
+        batch = synth.collate_np(tr, synth.minibatch_indices(step, n=2000, B=B, seed=7))
+        before = {k: v.detach().double().numpy().copy() for k, v in dqn.policy.state_dict().items()}
+        loss = dqn.update(batch, g[f"coins_B{B}"][step])
+        np.testing.assert_allclose(loss, g[f"loss_B{B}_s{step}"], rtol=1e-5)
+        for k, v in dqn.policy.state_dict().items():
+            d = v.detach().double().numpy() - before[k]
+            np.testing.assert_allclose(d.ravel()[:64], g[f"dslice_B{B}_s{step}_{k}"], rtol=2e-3, atol=2e-8, err_msg=k)
+        synced = all(torch.equal(a, b) for a, b in zip(dqn.policy.state_dict().values(), dqn.target.state_dict().values()))
+        assert synced == bool(g[f"synced_B{B}_s{step}"])
