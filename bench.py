@@ -13,12 +13,19 @@ The same JSON line also carries, as `dqn`, the second half of BASELINE's metric:
 3 forwards + loss + BPTT -> [RCCL all-reduce of the 724 KB gradient arena when N>1] -> clamp+Adam ->
 target-sync coin flip).  `--workload dqn` makes that the headline `value` instead.
 
+Timing: W warm-up steps, extended until at least --min-warm-s seconds of the same work have run (the shader clock falls from
+2.4 to ~1.6 GHz under sustained MFMA load: a cold 80 ms window is not a steady-state figure), then EXACTLY K steps between
+barrier + synchronize pairs.  With no flags K = 250 (> 1 s of work).  `sustained` repeats the measurement over a window of
+at least 1 s whatever K was.
+
 roofline: dominant kernel family = the tower's contraction kernels, conv_igemm* | conv1x1_wide* | conv3x3_patch* (layer by layer), stem_pool* and bneck* (whole
-res2 bottlenecks fused) (bound: bf16 MFMA, 2.5 PFLOP/s dense).  achieved = algorithmic conv FLOPs per launch /
-average launch duration, timed with HIP events on the launch stream inside the library
-(ivosw_profile_start/stop) over extra steps that run right after the timed region, so the events do not perturb
-`value`.  cpu_baseline: the oracle (torch-CPU restatement of the reference path, kind "port") on a bounded
-sample, rank 0, N=1 only.
+bottlenecks / stage runs fused) (bound: bf16 MFMA, 2.5 PFLOP/s dense).  achieved = algorithmic conv FLOPs per launch /
+average launch duration, where the family's time is measured INSIDE the timed region with one HIP-event pair per forward pass
+on the launch stream (ivosw_profile_span_*: stem .. last res5 kernel; the bbox / ROI kernels before and the pool+fc kernel after
+are outside the pair), so family time <= ms_per_step by construction and nothing is bracketed per launch.
+`checked`: after the timed region a sample of the B=256 scores is compared with the oracle on the CPU (and the fp32 parity
+mode, which is also timed: `fp32`); the line is not printed if they disagree.  cpu_baseline: torch-CPU restatements of the
+reference path (kind "port") on bounded samples, rank 0, N=1 only.
 """
 import argparse
 import ctypes
@@ -40,6 +47,8 @@ GFLOP_PER_FRAME = 10.779365376              # 5 389 682 688 MAC x 2 (SURVEY Appe
 CONV_LAUNCHES_PER_FRAME_CHUNK = 54           # stem + 53 tower convs, per chunk
 PEAK_BF16_TFLOPS = 2500.0                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+BF16_SCORE_RTOL = 5e-3                      # the bf16 mode's stated tolerance (tests/test_gpu_assess.py)
+DQN_GFLOP_PER_STEP = 10.5                    # 3 forwards + backward at B=128, T=25
 
 
 class AD(dict):
@@ -66,9 +75,26 @@ def dist_setup(n):
     return rank, world, dev, dist
 
 
-def timed(fn, steps, warmup, dev, dist):
+def timed(fn, steps, warmup, dev, dist, min_warm_s=0.0, before=None, after=None):
+    """W warm-up steps (extended to min_warm_s seconds of the same work), then exactly `steps` steps between barrier +
+    synchronize pairs; the max over ranks.  `before` / `after` run inside the bracket's host side but enqueue no kernels."""
+    t_w = time.perf_counter()
     for _ in range(warmup):
         fn()
+    torch.cuda.synchronize(dev)
+    def warm_enough():
+        el = time.perf_counter() - t_w
+        if dist is not None:                   # every rank must take the same decision (the step may contain a collective)
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            el = float(t.item())
+        return el >= min_warm_s
+    while min_warm_s > 0 and not warm_enough():
+        for _ in range(max(1, warmup)):
+            fn()
+        torch.cuda.synchronize(dev)
+    if before is not None:
+        before()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -79,6 +105,8 @@ def timed(fn, steps, warmup, dev, dist):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if after is not None:
+        after()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -103,31 +131,56 @@ def build_assess(args, rank, dev):
     return net, tf, tp
 
 
+def check_scores(scores, tf, tp, precision, pick):
+    """A sample of the timed batch against the oracle (CPU restatement of the reference) — outside the timed region."""
+    from oracle import assess_oracle as ao          # checker only
+    sd = ao.to_torch_sd(synth.assessnet_state_dict(0))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = ao.assess_forward(sd, tf[pick].cpu().numpy(), tp[pick].cpu().numpy()).reshape(-1)
+    got = scores.reshape(-1)[pick].cpu().numpy()
+    tol = BF16_SCORE_RTOL if precision == "bf16" else 1e-4
+    err = float(np.max(np.abs(got - ref) / np.abs(ref)))
+    if not (err <= tol):
+        raise SystemExit(f"bench.py: scores of the timed batch disagree with the oracle (worst rel err {err:.3e} > {tol}): no line printed")
+    return {"frames": len(pick), "worst_rel_err": float(f"{err:.3e}"), "tolerance": tol, "against": "oracle/assess_oracle.py (torch-CPU restatement of AssessNet.forward)"}
+
+
 def bench_assess(args, rank, world, dev, dist):
     net, tf, tp = build_assess(args, rank, dev)
+    lib = L.lib()
     out = {}
 
     def step():
         out["s"] = net(tf, tp)
-    dt = timed(step, args.steps, args.warmup, dev, dist)
+    tot, spans, cnt = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_int(0)
+    dt = timed(step, args.steps, args.warmup, dev, dist, args.min_warm_s,
+               before=lambda: lib.ivosw_profile_span_start(),
+               after=lambda: lib.ivosw_profile_span_stop(ctypes.byref(tot), ctypes.byref(spans), ctypes.byref(cnt)))
     assert torch.isfinite(out["s"]).all()
+    scores = out["s"].clone()
     fps = world * args.batch * args.steps / dt
-    # roofline leg: HIP events around every conv launch, separate steps
-    lib = L.lib()
-    psteps = max(1, min(3, args.steps))
-    lib.ivosw_profile_start()
-    for _ in range(psteps):
-        step()
+    assert spans.value == args.steps * -(-args.batch // net_chunk(args)), (spans.value, args.steps)     # one span per ROI chunk
+    conv_ms = tot.value / args.steps
+    launches = cnt.value // args.steps
+    # sustained: the same measurement over >= 1 s, whatever K was
+    sus = None
+    if dt < 1.0:
+        n = int(1.2 / (dt / args.steps)) + 1
+        sdt = timed(step, n, 0, dev, dist)
+        sus = {"value": round(world * args.batch * n / sdt, 1), "steps": n, "seconds": round(sdt, 3)}
+    else:
+        sus = {"value": round(fps, 1), "steps": args.steps, "seconds": round(dt, 3)}
     if args.layer_report and rank == 0:
+        lib.ivosw_profile_start()
+        for _ in range(3):
+            step()
         buf = ctypes.create_string_buffer(1 << 16)
         lib.ivosw_profile_report(buf, len(buf))
+        t2, c2 = ctypes.c_double(0), ctypes.c_int(0)
+        lib.ivosw_profile_stop(ctypes.byref(t2), ctypes.byref(c2))
         with open(args.layer_report, "w") as f:
-            f.write(f"# per-layer conv timing (HIP events, {psteps} steps, batch {args.batch}, chunk {args.chunk or 'default'}, {args.precision})\n")
+            f.write(f"# per-layer conv timing (HIP events around every launch, 3 steps, batch {args.batch}, chunk {args.chunk or 'default'}, {args.precision})\n")
             f.write(buf.value.decode())
-    tot, cnt = ctypes.c_double(0), ctypes.c_int(0)
-    lib.ivosw_profile_stop(ctypes.byref(tot), ctypes.byref(cnt))
-    conv_ms = tot.value / psteps
-    launches = cnt.value // psteps
     flops_step = GFLOP_PER_FRAME * 1e9 * args.batch
     achieved = flops_step / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
@@ -145,8 +198,45 @@ def bench_assess(args, rank, world, dev, dist):
             "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "hbm_GBps_of_family": hbm_gbps, "hbm_peak_GBps": 8000.0,
             "launches_per_step": launches, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
-            "flops_per_launch": flops_step / max(launches, 1), "kernel_ms_per_step": round(conv_ms, 3)}
-    return fps, dt, roof
+            "flops_per_launch": flops_step / max(launches, 1), "kernel_ms_per_step": round(conv_ms, 3),
+            "timing": "one HIP-event pair per forward pass around the tower's launches, inside the timed region (family time includes its own launch gaps)"}
+    extra = {"sustained": sus}
+    if rank == 0:
+        pick = [0, 37, 74, 111, 148, 185, 222, args.batch - 1] if args.batch >= 256 else list(range(min(8, args.batch)))
+        extra["checked"] = True
+        extra["check"] = check_scores(scores, tf, tp, args.precision, pick)
+        if args.precision == "bf16" and not args.no_fp32:
+            extra["fp32"] = bench_fp32(args, dev, tf, tp, scores, pick)
+    return fps, dt, roof, extra
+
+
+def net_chunk(args):
+    return args.chunk or (256 if args.precision == "bf16" else 16)
+
+
+def bench_fp32(args, dev, tf, tp, scores16, pick):
+    """The fp32 parity mode (the only mode that meets north_star's 1e-4) on the same batch: timed, and compared with the bf16 scores."""
+    from ivos_w_amd.models.assessment import AssessNet
+    net = AssessNet(precision="fp32")
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.assessnet_state_dict(0).items()})
+    net.to(dev).eval()
+    out = {}
+
+    def step():
+        out["s"] = net(tf, tp)
+    n = 4
+    dt = timed(step, n, 1, dev, None)
+    s32 = out["s"].reshape(-1)
+    rel = float(((scores16.reshape(-1) - s32).abs() / s32.abs()).max())
+    if not (rel <= BF16_SCORE_RTOL):
+        raise SystemExit(f"bench.py: bf16 scores differ from the fp32 parity mode by {rel:.3e} > {BF16_SCORE_RTOL}")
+    chk = check_scores(s32, tf, tp, "fp32", pick)
+    fps = args.batch * n / dt
+    tf_s = GFLOP_PER_FRAME * 1e9 * fps / 1e12
+    return {"value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(dt / n * 1e3, 2), "steps": n, "dtype": "f32",
+            "achieved_TFLOPs": round(tf_s, 2), "peak_TFLOPs": PEAK_F32_TFLOPS, "frac": round(tf_s / PEAK_F32_TFLOPS, 4),
+            "note": "whole-forward wall time (not kernel-only) against the fp32 MFMA peak", "bf16_vs_fp32_worst_rel": float(f"{rel:.3e}"),
+            "check": chk}
 
 
 def build_dqn(args, rank, dev):
@@ -163,21 +253,55 @@ def build_dqn(args, rank, dev):
 
 
 def bench_dqn(args, rank, world, dev, dist, steps, warmup):
+    """One step = minibatch indices (device RNG) -> ONE hipGraphLaunch {replay gather, 3 forwards + loss + BPTT, [N=1: clamp + Adam
+    with the device-side step]} -> [N>1: RCCL all-reduce of the 724 KB gradient arena, clamp + Adam] -> host coin -> target sync."""
+    from ivos_w_amd.models.agent import CapturedDqnStep
     agent, replay, gen = build_dqn(args, rank, dev)
     B = args.minibatch
+    fused = world == 1
+    if args.dqn_eager:
+        cap = None
+    else:
+        cap = CapturedDqnStep(agent, replay, B, fused=fused)
+    nrep = len(replay)
 
     def step():
-        idx = torch.randint(0, len(replay), (B,), device=dev, generator=gen)
-        agent.loss_and_grads(replay.sample(idx))
+        if cap is None:
+            idx = torch.randint(0, nrep, (B,), device=dev, generator=gen)
+            agent.loss_and_grads(replay.sample(idx))
+        else:
+            torch.randint(0, nrep, (B,), device=dev, generator=gen, out=cap.idx)
+            cap.launch()
         if world > 1:
             dist.all_reduce(agent.policy_net.flat_grad)
             agent.optimizer.grad_scale = 1.0 / world
-        agent.optimizer.step()
+        if cap is None or not fused:
+            agent.optimizer.step()
         if np.random.random() < agent.update_rate:
             agent.sync_target()
-    dt = timed(step, steps, warmup, dev, dist)
-    assert torch.isfinite(agent.policy_net.flat).all()
-    return world * steps / dt, dt
+    dt = timed(step, steps, warmup, dev, dist, min(args.min_warm_s, 0.5))
+    assert torch.isfinite(agent.policy_net.flat).all() and agent.optimizer.state["step"] >= steps + warmup
+    sps = world * steps / dt
+    per_gpu_tflops = DQN_GFLOP_PER_STEP * 1e9 * (sps / world) / 1e12
+    info = {"us_per_step": round(dt / steps * 1e6, 1), "graph": cap is not None,
+            "kernel_nodes_in_graph": cap.kernel_nodes if cap is not None else None,
+            "host_launches_per_step": (2 if fused else 4) if cap is not None else None,
+            "roofline": {"bound": "mfma", "achieved": round(per_gpu_tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(per_gpu_tflops / PEAK_F32_TFLOPS, 5), "traffic": None,
+                         "note": "whole step (10.5 GFLOP algorithmic, SURVEY 8d) / step wall time per GPU, against the fp32 MFMA peak: the step is a "
+                                 "chain of dependent launches (latency-bound), so this fraction is reported for completeness"}}
+    # Agent.action latency at evaluation size (N = 1, T = 104 frames: host state -> greedy index on the host)
+    if rank == 0:
+        state = synth.brain_inputs(1, 104, 3)[0]
+        agent.cfg = AD(agent.cfg, phase="eval")
+        for _ in range(5):
+            agent.action(state, verbose=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            agent.action(state, verbose=False)
+        info["action_latency_us_T104"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
+    return sps, dt, info
 
 
 def bench_jf(rank, world, dev, dist, steps=20, warmup=3, N=100, O=3):
@@ -263,66 +387,78 @@ def cpu_baseline_assess():
 
 
 def cpu_baseline_dqn():
-    from oracle import brain_oracle as bo
+    """the stock torch-CPU path (nn.Linear / nn.LSTMCell / autograd / optim.Adam assembled by own module definitions,
+    pinned against the reference's goldens in tests/test_oracle_brain.py) on the host cores."""
+    from oracle.torch_cpu_baseline import TorchDQN
     tr = synth.replay_transitions(n=2000, T=25, seed=2019)
-    P = synth.brain_state_dict(0)
-    Pt = {k: v.copy() for k, v in P.items()}
-    M = {k: np.zeros_like(v) for k, v in P.items()}
-    V = {k: np.zeros_like(v) for k, v in P.items()}
-    cfg = dict(gamma=0.95, lr=5e-6, weight_decay=5e-4, update_rate=0.05)
-    reps, t0 = 0, time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t0 < 8.0 and reps < 200):
-        batch = synth.collate_np(tr, synth.minibatch_indices(reps % 8, n=2000, B=128, seed=7))
-        bo.dqn_step(P, Pt, M, V, reps + 1, batch, cfg, 1.0)
-        reps += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(reps / dt, 2), "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x update_agent, minibatch 128, T=25, numpy oracle"}
+    best = None
+    for threads in sorted({min(8, os.cpu_count() or 1), min(32, os.cpu_count() or 1), os.cpu_count() or 1}):
+        # the step is ~1000 tiny ops: it stops scaling after a few threads, so several counts are tried and the best is reported
+        torch.set_num_threads(threads)
+        dqn = TorchDQN(synth.brain_state_dict(0), synth.brain_state_dict(0))
+        rs = np.random.RandomState(0)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < 4.0 and reps < 200):
+            batch = synth.collate_np(tr, synth.minibatch_indices(reps % 8, n=2000, B=128, seed=7))
+            dqn.update(batch, rs.random_sample())
+            reps += 1
+        v = reps / (time.perf_counter() - t0)
+        if best is None or v > best[0]:
+            best = (v, threads, reps)
+    return {"value": round(best[0], 2), "unit": "steps/s", "cores": best[1], "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"{best[2]} x update_agent, minibatch 128, T=25, torch-CPU (LSTMCell / autograd / Adam, the reference's operator sequence); "
+                      f"best of several thread counts"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--min-warm-s", type=float, default=1.0, help="extend the warm-up to at least this many seconds (steady-state clocks)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode sub-record")
+    ap.add_argument("--dqn-eager", action="store_true", help="DQN leg with eager launches instead of the captured HIP graph")
     ap.add_argument("--workload", choices=["assess", "dqn"], default="assess")
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (assessment)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--minibatch", type=int, default=128)
     ap.add_argument("--replay", type=int, default=50000)
-    ap.add_argument("--dqn-steps", type=int, default=200)
+    ap.add_argument("--dqn-steps", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-report", default="", help="write a per-conv-layer timing table (HIP events) to this file")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
     rank, world, dev, dist = dist_setup(args.gpus)
-    L.lib()
+    lib = L.lib()
+    # ablation guard: the measured library must be the default build, with no debug switch in the environment
+    if lib.ivosw_ablation_build() != 0 or os.environ.get("IVOSW_DEBUG_CONV", "0") not in ("", "0") or os.environ.get("IVOSW_TUNE_BDBG", "0") not in ("", "0"):
+        raise SystemExit("bench.py: ablation switches are compiled in or set (IVOSW_ABLATION build / IVOSW_DEBUG_CONV / IVOSW_TUNE_BDBG): refusing to measure")
 
     line = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic"}
     if args.workload == "assess":
-        fps, dt, roof = bench_assess(args, rank, world, dev, dist)
-        dqn_sps, dqn_dt = bench_dqn(args, rank, world, dev, dist, args.dqn_steps, 20)
+        fps, dt, roof, extra = bench_assess(args, rank, world, dev, dist)
+        dqn_sps, dqn_dt, dqn_info = bench_dqn(args, rank, world, dev, dist, args.dqn_steps, 20)
         line.update({"metric": "assessed_frames_per_sec", "value": round(fps, 1), "unit": "frames/s",
                      "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": args.precision,
                      "config": {"workload": f"AssessNet.forward, batch {args.batch} x 480x854 frame+mask per GPU (BASELINE configs[1])",
                                 "batch_per_gpu": args.batch, "chunk": args.chunk or "default", "parallelism": f"frames sharded x{world}"},
-                     "roofline": roof,
-                     "dqn": {"metric": "dqn_agent_steps_per_sec", "value": round(dqn_sps, 1), "unit": "minibatch-steps/s (all ranks)",
-                             "transitions_per_sec": round(dqn_sps * args.minibatch, 1), "minibatch_per_gpu": args.minibatch,
-                             "replay": args.replay, "T": 25, "steps": args.dqn_steps, "us_per_step": round(dqn_dt / args.dqn_steps * 1e6, 1),
-                             "dtype": "f32", "collective": "rccl all_reduce(724KB)" if world > 1 else None}})
+                     "roofline": roof, "ablation_build": 0,
+                     "dqn": dict({"metric": "dqn_agent_steps_per_sec", "value": round(dqn_sps, 1), "unit": "minibatch-steps/s (all ranks)",
+                                  "transitions_per_sec": round(dqn_sps * args.minibatch, 1), "minibatch_per_gpu": args.minibatch,
+                                  "replay": args.replay, "T": 25, "steps": args.dqn_steps,
+                                  "dtype": "f32", "collective": "rccl all_reduce(724KB)" if world > 1 else None}, **dqn_info)})
+        line.update(extra)
     else:
-        sps, dt = bench_dqn(args, rank, world, dev, dist, args.steps, args.warmup)
+        sps, dt, info = bench_dqn(args, rank, world, dev, dist, args.steps, args.warmup)
+        roof = info.pop("roofline")
         line.update({"metric": "dqn_agent_steps_per_sec", "value": round(sps, 1), "unit": "minibatch-steps/s",
                      "ms_per_step": round(dt / args.steps * 1e3, 4), "dtype": "f32",
                      "config": {"workload": f"Double-DQN update, replay {args.replay}, minibatch {args.minibatch}/GPU, T=25 (BASELINE configs[2]/[3])",
                                 "parallelism": f"dp{world}"},
-                     "roofline": {"bound": "mfma", "achieved": round(10.5e9 * sps / world / 1e12, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(10.5e9 * sps / world / 1e12 / PEAK_F32_TFLOPS, 5), "traffic": None,
-                                  "note": "whole-step algorithmic 10.5 GFLOP / step time: the step is latency-bound (SURVEY §8d)"}})
+                     "roofline": roof, "ablation_build": 0}, **info)
     if args.workload == "assess":
         line["jf"] = bench_jf(rank, world, dev, dist)
         line["seg_epilogue"] = bench_seg(rank, world, dev, dist)

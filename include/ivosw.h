@@ -73,8 +73,8 @@ int ivosw_clamp_adam(float* params, const float* grads, float* exp_avg, float* e
                      int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                      float clamp, float grad_scale, ivosw_stream_t stream);
 /* The same update with Adam's step counter and bias corrections kept on the device (adam_state: ivosw_adam_state_bytes()
- * bytes, zero-initialised = step 0; float64 running products of beta1 / beta2), so that a HIP graph that captured the call
- * replays correctly: every call (or replay) advances the step by one.                                                 */
+ * bytes, zero-initialised = step 0; the step counter is the int32 at byte offset 16, which is all a caller writes to resume
+ * from step k), so that a HIP graph that captured the call replays correctly: every call (or replay) advances the step by one.                                                 */
 size_t ivosw_adam_state_bytes(void);
 int ivosw_clamp_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, void* adam_state,
                          float lr, float beta1, float beta2, float eps, float weight_decay, float clamp,
@@ -162,6 +162,18 @@ int ivosw_seg_epilogue(const float* logits, int n, int C, int hs, int ws, int H,
                        long probs_stride_n, long probs_stride_c, int64_t* label_i64, uint8_t* label_u8,
                        float* label_f32, ivosw_stream_t stream);
 
+/* ------------------------------------------------------------------ launch-sequence capture ---- */
+/* HIP-graph capture of any sequence of the calls above on one stream (not in the reference: it replaces the ~40 host
+ * launches per Agent.update_agent step, models/agent.py:128-160, by ONE hipGraphLaunch).  begin puts `stream` (non-null)
+ * into capture; every ivosw_* call made on it until end is recorded instead of executed; end instantiates the graph and
+ * reports its kernel-node count.  All device pointers passed during capture must stay valid for the life of the handle;
+ * per-step scalars that change (Adam's step) live on the device (ivosw_clamp_adam_dev).  The handle is a host object.  */
+typedef void* ivosw_graph_t;
+int ivosw_graph_begin(ivosw_stream_t stream);
+int ivosw_graph_end(ivosw_stream_t stream, ivosw_graph_t* out, int* kernel_nodes);
+int ivosw_graph_launch(ivosw_graph_t g, ivosw_stream_t stream);
+int ivosw_graph_destroy(ivosw_graph_t g);
+
 /* ------------------------------------------------------------------ measurement hooks ---------- */
 /* Not part of the reference surface: bench.py's roofline leg.  Between start and stop every launch of
  * the dominant kernel family (conv_igemm*, conv1x1_wide*, conv3x3_patch*, bneck*, stem_pool*) is bracketed by hipEvents on the launch stream; stop
@@ -179,6 +191,9 @@ int ivosw_profile_report(char* buf, size_t cap);
 /* Tuning/test hook: override a named integer tunable (otherwise read from the environment variable
  * IVOSW_TUNE_<KEY>).  Keys: FUSE (1 = whole-bottleneck fused kernels in bf16 mode, 0 = layer by layer), WS, NK. */
 int ivosw_tune_set(const char* key, int value);
+/* 1 when the library was built with -DIVOSW_ABLATION=1 (the ablation switches IVOSW_DEBUG_CONV / BDBG are compiled in and can
+ * skip MFMAs, loads or stores); the default build returns 0 and contains none of them.  bench.py refuses to run on 1.   */
+int ivosw_ablation_build(void);
 /* Tuning probe: ONE fused bottleneck (wd/bd NULL: identity block, else the stride-1 downsample block)
  * (x [B,H,W,Cin] bf16 -> y [B,H,W,4*Cmid] bf16; weights packed
  * K-major bf16 with fp32 biases as ivosw_assess_pack lays them out) with s_memtime stamps at the phase

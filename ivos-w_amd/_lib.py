@@ -42,12 +42,17 @@ SIGNATURES = {
     "ivosw_jf_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "ivosw_jf_counts": (_i, [_p, _p, _i, _i, _i, C.c_char_p, _i, _i, _p, _p, _sz, _p]),
     "ivosw_seg_epilogue": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, C.c_long, C.c_long, _p, _p, _p, _p]),
+    "ivosw_graph_begin": (_i, [_p]),
+    "ivosw_graph_end": (_i, [_p, C.POINTER(_p), C.POINTER(_i)]),
+    "ivosw_graph_launch": (_i, [_p, _p]),
+    "ivosw_graph_destroy": (_i, [_p]),
     "ivosw_profile_start": (_i, []),
     "ivosw_profile_span_start": (_i, []),
     "ivosw_profile_span_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i)]),
     "ivosw_profile_stop": (_i, [C.POINTER(C.c_double), C.POINTER(_i)]),
     "ivosw_profile_report": (_i, [C.c_char_p, _sz]),
     "ivosw_tune_set": (_i, [C.c_char_p, _i]),
+    "ivosw_ablation_build": (_i, []),
     "ivosw_bneck_probe": (_i, [_p] * 11 + [_i] * 5 + [_p, _p]),
     "ivosw_bneck_wide_probe": (_i, [_p] * 9 + [_i] * 5 + [_p, _p]),
 }
@@ -107,3 +112,48 @@ class Workspace:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         return self.buf
+
+
+class Graph:
+    """A captured launch sequence (ivosw_graph_*): ``with Graph.capture(device) as g: <ivosw calls via stream_ptr(device)>``
+    records every library call made inside the block on a private stream into one HIP graph; ``g.launch()`` replays it on
+    the caller's current stream.  No torch allocation may happen inside the block: hand in preallocated tensors."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.handle = None
+        self.kernel_nodes = 0
+        self._stream = None
+        self._ctx = None
+
+    @classmethod
+    def capture(cls, device):
+        return cls(device)
+
+    def __enter__(self):
+        self._stream = torch.cuda.Stream(self.device)
+        self._stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._ctx = torch.cuda.stream(self._stream)
+        self._ctx.__enter__()
+        check(lib().ivosw_graph_begin(C.c_void_p(self._stream.cuda_stream)), "graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h, n = C.c_void_p(), C.c_int(0)
+        rc = lib().ivosw_graph_end(C.c_void_p(self._stream.cuda_stream), C.byref(h), C.byref(n))
+        self._ctx.__exit__(et, ev, tb)
+        if et is None:
+            check(rc, "graph_end")
+            self.handle, self.kernel_nodes = h, n.value
+        return False
+
+    def launch(self):
+        check(lib().ivosw_graph_launch(self.handle, stream_ptr(self.device)), "graph_launch")
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                lib().ivosw_graph_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None

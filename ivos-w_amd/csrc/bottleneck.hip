@@ -64,7 +64,7 @@ __device__ __forceinline__ int wave_scratch(int wave) { return wave < 6 ? wave *
 
 // ablation: MFMA off (operands kept live so nothing upstream is dead code)
 __device__ __forceinline__ f32x16 mfma_dbg(u32x4 a, u32x4 b, f32x16 c, int dbg) {
-    if (dbg & 8) {
+    if (ABL(dbg, 8)) {
         asm volatile("" ::"v"(a), "v"(b));
         return c;
     }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int g = wave + 8 * i;
-            const bf16_t* src = abase[i] + (((okmask >> i) & 1u) && !(p.debug & 4) ? kt * 64 : 0);
+            const bf16_t* src = abase[i] + (((okmask >> i) & 1u) && !ABL(p.debug, 4) ? kt * 64 : 0);
             dma16(src, lds + (g < NGA ? st + WK_BYTES + g * 1024 : DUMMY_OFF));
         }
         dma16(wa_src + kt * 64, lds + st + wave * 1024);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
                     unsigned pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pk[k] = pack2_bf16(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
-                    if (!(p.debug & 2) || pk[0] == 0x12345678u) {
+                    if (!ABL(p.debug, 2) || pk[0] == 0x12345678u) {
                         u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
                         if (p.nt) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)));
                         else *reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)) = ov;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
                     const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 64 + (((2 * u) ^ (pr & 15)) << 2));
                     const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 64 + (((2 * u + 1) ^ (pr & 15)) << 2));
                     const u32x4 r4 = rr[cp * 2 + q][it];
-                    const unsigned w4[4] = {(p.debug & 1) ? 0u : r4[0], r4[1], r4[2], r4[3]};
+                    const unsigned w4[4] = {ABL(p.debug, 1) ? 0u : r4[0], r4[1], r4[2], r4[3]};
                     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     unsigned pk[4];
 #pragma unroll
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
                         const float hi = fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f);
                         pk[k] = pack2_bf16(lo, hi);
                     }
-                    if (!(p.debug & 2) || pk[0] == 0x12345678u) {
+                    if (!ABL(p.debug, 2) || pk[0] == 0x12345678u) {
                         u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
                         if (p.nt) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)));
                         else *reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)) = ov;

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace ivosw {
@@ -68,3 +70,78 @@ extern "C" int ivosw_tune_set(const char* key, int value) {
 
 extern "C" const char* ivosw_last_error(void) { return ivosw::g_err; }
 extern "C" int ivosw_version(void) { return 100; }
+extern "C" int ivosw_ablation_build(void) { return IVOSW_ABLATION; }
+
+
+// ---------------------------------------------------------------- HIP graph capture of a launch sequence
+// A DQN step is ~40 dependent launches of 5-30 us whose host enqueue (170-250 us) is as long as the step: capturing the
+// calls once and replaying the graph costs one hipGraphLaunch per step.  The calls between begin and end are the ordinary
+// entry points of this library on `stream` (they fork / join the library's helper stream with events, which joins the
+// capture); nothing is allocated on the device, the graph is a host object owned by the handle.
+namespace {
+struct GraphHandle {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int kernel_nodes = 0, nodes = 0;
+};
+}  // namespace
+
+extern "C" int ivosw_graph_begin(ivosw_stream_t stream) {
+    IVOSW_REQUIRE(stream != nullptr, "capture needs an explicit (non-null) stream");
+    hipError_t e = hipStreamBeginCapture(ivosw::as_stream(stream), hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        ivosw::set_error("ivosw_graph_begin: %s", hipGetErrorString(e));
+        return IVOSW_ERR_LAUNCH;
+    }
+    return IVOSW_OK;
+}
+
+extern "C" int ivosw_graph_end(ivosw_stream_t stream, ivosw_graph_t* out, int* kernel_nodes) {
+    IVOSW_REQUIRE(stream != nullptr && out, "null pointer");
+    GraphHandle* h = new GraphHandle();
+    hipError_t e = hipStreamEndCapture(ivosw::as_stream(stream), &h->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&h->exec, h->graph, nullptr, nullptr, 0);
+    if (e == hipSuccess) {
+        size_t n = 0;
+        if (hipGraphGetNodes(h->graph, nullptr, &n) == hipSuccess && n > 0) {
+            std::vector<hipGraphNode_t> nodes(n);
+            if (hipGraphGetNodes(h->graph, nodes.data(), &n) == hipSuccess) {
+                h->nodes = (int)n;
+                for (size_t i = 0; i < n; ++i) {
+                    hipGraphNodeType t;
+                    if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++h->kernel_nodes;
+                }
+            }
+        }
+    }
+    if (e != hipSuccess) {
+        ivosw::set_error("ivosw_graph_end: %s", hipGetErrorString(e));
+        if (h->exec) (void)hipGraphExecDestroy(h->exec);
+        if (h->graph) (void)hipGraphDestroy(h->graph);
+        delete h;
+        (void)hipGetLastError();
+        return IVOSW_ERR_LAUNCH;
+    }
+    if (kernel_nodes) *kernel_nodes = h->kernel_nodes;
+    *out = h;
+    return IVOSW_OK;
+}
+
+extern "C" int ivosw_graph_launch(ivosw_graph_t g, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(g, "null graph");
+    hipError_t e = hipGraphLaunch(static_cast<GraphHandle*>(g)->exec, ivosw::as_stream(stream));
+    if (e != hipSuccess) {
+        ivosw::set_error("ivosw_graph_launch: %s", hipGetErrorString(e));
+        return IVOSW_ERR_LAUNCH;
+    }
+    return IVOSW_OK;
+}
+
+extern "C" int ivosw_graph_destroy(ivosw_graph_t g) {
+    if (!g) return IVOSW_OK;
+    GraphHandle* h = static_cast<GraphHandle*>(g);
+    if (h->exec) (void)hipGraphExecDestroy(h->exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    delete h;
+    return IVOSW_OK;
+}

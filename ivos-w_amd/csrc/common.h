@@ -51,6 +51,14 @@ struct DeviceScope {
         }                                                                                          \
     } while (0)
 
+// Ablation switches (skip MFMAs / stores / loads to time the rest; tools/ablate_bneck.sh, IVOSW_DEBUG_CONV, tunable BDBG) exist
+// only in builds made with -DIVOSW_ABLATION=1 (IVOSW_ABLATION=1 python ivos-w_amd/build.py --force).  The default build
+// compiles every test out; ivosw_ablation_build() reports which one is loaded and bench.py refuses to run on the other.
+#ifndef IVOSW_ABLATION
+#define IVOSW_ABLATION 0
+#endif
+#define ABL(dbg, bits) (IVOSW_ABLATION && ((dbg) & (bits)))
+
 constexpr int WAVE = 64;
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

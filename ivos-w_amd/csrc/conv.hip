@@ -49,7 +49,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
         const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
         float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
         const long o = (long)m * p.Cout + n;
-        if (p.debug & 1) { if (v0.x == 1.2345e30f) Y[o] = T(0); continue; }
+        if ABL(p.debug, 1) { if (v0.x == 1.2345e30f) Y[o] = T(0); continue; }
         if constexpr (ES == 2) {
             if (R) {
                 uint4 rr;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();   // every wave's share of tile kt has landed; every wave is done with tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + S - 1 < nk && !(p.debug & 4)) issue(kt + S - 1, fill);   // refill the slot tile kt-1 just vacated
+        if (kt + S - 1 < nk && !ABL(p.debug, 4)) issue(kt + S - 1, fill);   // refill the slot tile kt-1 just vacated
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
         u32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int ks, int buf) {
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
         for (int ks = 0; ks < 4; ++ks) {
             lds_wait();                                  // fragments of K-step ks are in registers
             if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);  // next K-step's reads fly under this step's MFMAs
-            if (p.debug & 2) continue;
+            if ABL(p.debug, 2) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -568,7 +568,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (p.debug & 8) continue;                   // ablation: loaders + barriers only (pure fill rate of the real access pattern)
+        if ABL(p.debug, 8) continue;                   // ablation: loaders + barriers only (pure fill rate of the real access pattern)
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
         u32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int ks, int buf) {
@@ -583,7 +583,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
         for (int ks = 0; ks < 4; ++ks) {
             lds_wait();
             if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);
-            if (p.debug & 2) continue;
+            if ABL(p.debug, 2) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
     for (int j = 0; j < nj; ++j) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (p.debug & 8) continue;                           // ablation: loaders + barriers only
+        if ABL(p.debug, 8) continue;                           // ablation: loaders + barriers only
         const unsigned a_base = lds_base + (c & 1) * PB, b_base = lds_base + W_OFF + (j % WR) * WSLOT;
         const int ky = t / 3, kx = t - ky * 3;
         unsigned arow[TM], asw[TM];
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
         for (int ks = 0; ks < 4; ++ks) {
             lds_wait();
             if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);
-            if (p.debug & 2) {                               // ablation: fragment reads without the MFMAs
+            if ABL(p.debug, 2) {                               // ablation: fragment reads without the MFMAs
                 asm volatile("" ::"v"(fa[ks & 1][0]), "v"(fa[ks & 1][1]), "v"(fb[ks & 1][0]), "v"(fb[ks & 1][1]));
                 continue;
             }

@@ -78,7 +78,8 @@ __global__ void quality_state_kernel(const float* __restrict__ scores, int n_obj
 }
 
 // Adam's step counter and bias corrections kept ON the device, so that a captured HIP graph of the DQN step replays
-// correctly: tick advances {step, beta1^t, beta2^t} (float64 running products) and publishes step_size / sqrt(bc2).
+// correctly: tick advances step, evaluates beta1^t / beta2^t in float64 and publishes step_size / sqrt(bc2).
+// Layout (32 bytes): the step counter is the int32 at byte 16; a caller resumes from host step k by writing k there.
 struct AdamDevState {
     double b1t, b2t;
     int step;
@@ -87,10 +88,10 @@ struct AdamDevState {
 __global__ void adam_tick_kernel(AdamDevState* st, float lr, float beta1, float beta2) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     AdamDevState s = *st;
-    if (s.step == 0) { s.b1t = 1.0; s.b2t = 1.0; }
     s.step += 1;
-    s.b1t *= (double)beta1;
-    s.b2t *= (double)beta2;
+    // the same float64 expressions ivosw_clamp_adam evaluates on the host from its `step` argument
+    s.b1t = pow((double)beta1, (double)s.step);
+    s.b2t = pow((double)beta2, (double)s.step);
     s.step_size = (float)((double)lr / (1.0 - s.b1t));
     s.bc2_sqrt = (float)sqrt(1.0 - s.b2t);
     *st = s;

@@ -116,9 +116,35 @@ class FusedClampAdam:
                                          g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                          g["clamp"], self.grad_scale, L.stream_ptr(b.flat.device)), "clamp_adam")
 
+    # -- device-side step state (what a captured HIP graph replays; ivosw_clamp_adam_dev) -------------------------------
+    def dev_state(self):
+        """The 32-byte Adam step state on the device, (re)synchronised with the host step counter."""
+        self._ensure()
+        dev = self.brain.flat.device
+        ds = self.state.get("dev")
+        if ds is None or ds.device != dev:
+            ds = torch.zeros(L.lib().ivosw_adam_state_bytes(), dtype=torch.uint8, device=dev)
+            self.state["dev"], self.state["dev_step"] = ds, 0
+        if self.state["dev_step"] != self.state["step"]:
+            ds[16:20].copy_(torch.from_numpy(np.array([self.state["step"]], dtype=np.int32).view(np.uint8)))
+            self.state["dev_step"] = self.state["step"]
+        return ds
+
+    def enqueue_dev_step(self):
+        """ivosw_clamp_adam_dev on the current stream (inside a capture: recorded); the caller bumps the host counter per replay."""
+        g, b = self.param_groups[0], self.brain
+        L.check(L.lib().ivosw_clamp_adam_dev(L.dptr(b.flat), L.dptr(b.flat_grad), L.dptr(self.state["exp_avg"]),
+                                             L.dptr(self.state["exp_avg_sq"]), L.BRAIN_NPARAMS, L.dptr(self.state["dev"]),
+                                             g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], g["clamp"],
+                                             self.grad_scale, L.stream_ptr(b.flat.device)), "clamp_adam_dev")
+
+    def note_dev_steps(self, n=1):
+        self.state["step"] += n
+        self.state["dev_step"] = self.state["step"]
+
     def state_dict(self):
         self._ensure()
-        return dict(state={k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state.items()},
+        return dict(state={k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state.items() if not k.startswith("dev")},
                     param_groups=[{k: v for k, v in self.param_groups[0].items() if k != "params"}])
 
     def load_state_dict(self, sd):
@@ -205,8 +231,8 @@ class Agent(nn.Module):
         if world > 1:
             # synchronous data parallel: sum over ranks (RCCL over xGMI), average inside the Adam kernel;
             # the clamp therefore sees the averaged gradient, as a single large batch would
-            dist.all_reduce(self.policy_net.flat_grad)
-            self.optimizer.grad_scale = 1.0 / world
+            from .. import parallel
+            self.optimizer.grad_scale = parallel.allreduce_grads(self.policy_net.flat_grad)
         self._update_avg_loss(loss)
         self.optimizer.step()
         # hard target sync with probability update_rate; np.random is seeded identically on every rank
@@ -278,3 +304,61 @@ class Agent(nn.Module):
         self.memory_pool.push(state, old_frame, next_state, reward_step, reward_done, is_done, state_iou,
                               next_state_iou, annotated_frames_str, next_annotated_frames_str)
         self.memory_pool.push_to_csv(report_save_dir)
+
+
+class CapturedDqnStep:
+    """One Double-DQN training step as ONE HIP-graph launch (models/agent.py:128-160 minus the host coin flip):
+
+        replay gather (minibatch indices read from ``self.idx`` on the device) -> 3 forwards + loss + BPTT
+        -> [fused=True: clamp + Adam with the step counter on the device]
+
+    With fused=False the graph stops at the gradients, for the data-parallel step (all-reduce, then the eager clamp+Adam).
+    Replaces ~40 host launches (170-250 us of enqueue per step) by one hipGraphLaunch.  The arithmetic is the eager path's:
+    the same entry points are recorded, so results are bit-identical to ``Agent.loss_and_grads`` + ``optimizer.step``."""
+
+    def __init__(self, agent, replay, B, fused=True):
+        dev = torch.device(agent.device)
+        self.agent, self.replay, self.B, self.fused = agent, replay, B, fused
+        T = replay.T
+        lib = L.lib()
+        self.idx = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.state = torch.empty(B, T, 2, dtype=torch.float32, device=dev)
+        self.new_state = torch.empty_like(self.state)
+        self.action = torch.empty(B, dtype=torch.int64, device=dev)
+        self.r_step = torch.empty(B, dtype=torch.float32, device=dev)
+        self.r_done = torch.empty_like(self.r_step)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        nbytes = lib.ivosw_dqn_ws_bytes(B, T)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        pn, tn, opt = agent.policy_net, agent.target_net, agent.optimizer
+        if fused:
+            opt.dev_state()
+        self._keys = (pn.flat.data_ptr(), tn.flat.data_ptr(), pn.flat_grad.data_ptr())
+        torch.cuda.synchronize(dev)
+        with L.Graph.capture(dev) as g:
+            st = L.stream_ptr(dev)
+            r = replay
+            L.check(lib.ivosw_replay_gather(L.dptr(r.old_iou), L.dptr(r.new_iou), L.dptr(r.ann), L.dptr(r.next_ann),
+                                            L.dptr(r.action), L.dptr(r.reward_step), L.dptr(r.reward_done), L.dptr(self.idx), B, T,
+                                            L.dptr(self.state), L.dptr(self.new_state), L.dptr(self.action), L.dptr(self.r_step),
+                                            L.dptr(self.r_done), st), "replay_gather")
+            L.check(lib.ivosw_dqn_loss_grad(L.dptr(pn.flat), L.dptr(tn.flat), L.dptr(self.state), L.dptr(self.new_state),
+                                            L.dptr(self.action), L.dptr(self.r_step), L.dptr(self.r_done), B, T,
+                                            float(np.float32(agent.GAMMA)), L.dptr(pn.flat_grad), L.dptr(self.loss),
+                                            L.dptr(self.ws), nbytes, st), "dqn_loss_grad")
+            if fused:
+                opt.enqueue_dev_step()
+        self.graph = g
+        self.kernel_nodes = g.kernel_nodes
+
+    def launch(self):
+        """Enqueue one step on the current stream; ``self.loss`` holds the device loss afterwards."""
+        a = self.agent
+        if self._keys != (a.policy_net.flat.data_ptr(), a.target_net.flat.data_ptr(), a.policy_net.flat_grad.data_ptr()):
+            raise RuntimeError("the parameter arenas moved (.to() / re-pack) after capture: build a new CapturedDqnStep")
+        if self.fused:
+            a.optimizer.dev_state()              # resync if an eager step ran in between
+        self.graph.launch()
+        if self.fused:
+            a.optimizer.note_dev_steps(1)
+        return self.loss

@@ -63,7 +63,13 @@ def allreduce_grads(flat_grad):
     """Sum the flat gradient arena over ranks in place; returns the scale (1/world) the optimizer must apply."""
     w = world()
     if w > 1:
-        dist.all_reduce(flat_grad)
+        if flat_grad.is_cuda and dist.get_backend() == "gloo":
+            # hosts without RCCL (and the two-ranks-on-one-GPU test): stage the 724 KB arena through pinned host memory
+            h = flat_grad.to("cpu")
+            dist.all_reduce(h)
+            flat_grad.copy_(h)
+        else:
+            dist.all_reduce(flat_grad)        # RCCL over xGMI
     return 1.0 / w
 
 

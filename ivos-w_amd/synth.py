@@ -81,7 +81,9 @@ def assessnet_key_shapes():
     return ks
 
 
-def assessnet_state_dict(seed=0):
+def assessnet_state_dict(seed=0, spread=False):
+    """``spread``: a second recipe whose scores differ widely from frame to frame (the default recipe's last-BN gammas x 0.2 and
+    default-size fc1 give nearly constant scores, which tests ranking decisions poorly): last-BN gammas x 0.5, fc1 weights x 6."""
     rs = np.random.RandomState(seed)
     sd = OrderedDict()
     for k, s, kind in assessnet_key_shapes():
@@ -97,7 +99,7 @@ def assessnet_state_dict(seed=0):
         elif kind in ("gamma", "gamma_last"):
             v = rs.uniform(0.5, 1.0, s).astype(np.float32)
             if kind == "gamma_last":
-                v *= np.float32(0.2)
+                v *= np.float32(0.5 if spread else 0.2)
         elif kind == "beta":
             v = rs.uniform(-0.1, 0.1, s).astype(np.float32)
         elif kind == "rmean":
@@ -109,6 +111,8 @@ def assessnet_state_dict(seed=0):
         elif kind == "fc":
             b = 1.0 / np.sqrt(2048.0)
             v = rs.uniform(-b, b, s).astype(np.float32)
+            if spread and len(s) == 2:
+                v *= np.float32(6.0)
         else:  # pragma: no cover
             raise KeyError(kind)
         sd[k] = v

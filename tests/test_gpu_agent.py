@@ -69,7 +69,10 @@ def test_action_is_first_argmax(dev, golden_dir):
     assert int(a) == int(g["argmax_1_104"][0]) and agent.steps_done == 1
 
 
-@pytest.mark.parametrize("B,T", [(32, 25), (128, 25), (5, 9), (1, 3)])
+# B > 128: 2*B rows > 256 puts R = 2 / R = 4 rows of the recurrence on one workgroup, in the kept-state forward AND in
+# lstm_bwd_kernel<2> / <4> (per-row loss step, zero-fill past the loss frame, shared LDS partials); the synthetic actions are
+# random, so the rows of a workgroup stop at different steps
+@pytest.mark.parametrize("B,T", [(32, 25), (128, 25), (5, 9), (1, 3), (129, 25), (200, 9), (300, 25)])
 def test_loss_and_grads_vs_oracle(dev, B, T):
     from ivos_w_amd.models.agent import Agent
     from oracle import brain_oracle as bo
@@ -182,3 +185,68 @@ def test_bad_args_fail_loudly(dev):
         Brain()(torch.zeros(1, 5, 2))                       # CPU tensor: no fallback
     rc = L.lib().ivosw_brain_forward(None, None, 1, 1, None, None, 0, None)
     assert rc < 0 and b"null" in L.lib().ivosw_last_error()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_captured_step_is_bit_identical_to_eager(dev, fused):
+    """ONE hipGraphLaunch per step (CapturedDqnStep: gather -> loss/grads -> [clamp+Adam with the device-side step]) against the
+    eager launches, 6 steps from the same start: loss, gradients, parameters and Adam moments bit for bit; an eager step
+    in the middle of the captured run (host-side step counter) resynchronises the device counter."""
+    from ivos_w_amd.models.agent import Agent, CapturedDqnStep
+    from ivos_w_amd.models.momory_pool import DeviceReplay
+    tr = synth.replay_transitions(n=3000, T=25, seed=2019)
+    rp = DeviceReplay(tr, dev)
+    B = 128
+
+    def fresh():
+        a = Agent(dev, cfg())
+        load_brain(a.policy_net, 0)
+        load_brain(a.target_net, 1)
+        return a
+    idxs = [torch.from_numpy(synth.minibatch_indices(s, n=3000, B=B, seed=7)).to(dev) for s in range(6)]
+    eager, cap = fresh(), fresh()
+    step = CapturedDqnStep(cap, rp, B, fused=fused)
+    assert step.kernel_nodes >= 20                         # the whole launch chain sits in the graph
+    for s, idx in enumerate(idxs):
+        l0 = eager.loss_and_grads(rp.sample(idx)).clone()
+        g0 = eager.policy_net.flat_grad.clone()
+        eager.optimizer.step()
+        step.idx.copy_(idx)
+        if s == 3:                                         # an eager step on the captured agent: same arithmetic, host-side counter
+            cap.loss_and_grads(rp.sample(idx))
+            l1, g1 = cap._loss_dev.clone(), cap.policy_net.flat_grad.clone()
+            cap.optimizer.step()
+        else:
+            l1 = step.launch().clone()
+            g1 = cap.policy_net.flat_grad.clone()
+            if not fused:
+                cap.optimizer.step()
+        assert torch.equal(l0, l1) and torch.equal(g0, g1), s
+        assert torch.equal(eager.policy_net.flat, cap.policy_net.flat), s
+        assert torch.equal(eager.optimizer.state["exp_avg_sq"], cap.optimizer.state["exp_avg_sq"]), s
+        assert eager.optimizer.state["step"] == cap.optimizer.state["step"] == s + 1
+
+
+def test_entry_points_run_on_the_buffers_device_not_the_current_one(dev):
+    """The reference builds torch.device(f'cuda:{gpu_id}') and never calls set_device (eval_agent_manet.py:63): every C-ABI
+    entry switches to the device that owns its buffers.  With one visible GPU the check is that a call made while a
+    different *stream context* / default device is current still lands on the tensors' device and restores the caller's."""
+    from ivos_w_amd.models.agent import Brain
+    n = torch.cuda.device_count()
+    target = torch.device("cuda", n - 1)
+    net = Brain().to(target)
+    load_brain(net, 0)
+    x = torch.Tensor(synth.brain_inputs(2, 9, 1)).to(target)
+    with torch.cuda.device(0):
+        q = net(x)
+        assert torch.cuda.current_device() == 0
+    assert q.device == target and torch.isfinite(q).all()
+    from oracle import brain_oracle as bo
+    np.testing.assert_allclose(q.cpu().numpy(), bo.brain_forward(synth.brain_state_dict(0), synth.brain_inputs(2, 9, 1).astype(np.float32)),
+                               rtol=1e-4, atol=1e-6)
+    # a host pointer is rejected, not dereferenced
+    from ivos_w_amd import _lib as L
+    import ctypes
+    host = (ctypes.c_float * 8)()
+    assert L.lib().ivosw_brain_argmax(ctypes.cast(host, ctypes.c_void_p), 1, 8, ctypes.cast(host, ctypes.c_void_p), None) == -1
+    assert b"not a device pointer" in L.lib().ivosw_last_error()

@@ -5,8 +5,8 @@ tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --dqn-steps 20"
-PASSES=5   # warmup 1 + timed 2 + 2 roofline passes (bench.py: psteps = min(3, steps))
+BENCH="python bench.py --steps 4 --warmup 1 --min-warm-s 0 --no-fp32 --no-cpu-baseline --dqn-steps 20"
+PASSES=5   # warmup 1 + timed 4 (the span timing runs inside the timed region; --no-fp32 keeps the fp32 conv_igemm launches out of the family)
 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- $BENCH > $out/bench_trace.log 2>&1
 db=$(ls $out/trace/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocprof_summary.py $db > $out/kernel_trace_summary.txt
@@ -14,7 +14,7 @@ rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- $BENCH 
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- $BENCH > $out/bench_write.log 2>&1
 python tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv "conv_igemm|conv1x1_wide|bneck|conv3x3_patch|stem_pool" $PASSES $out/pmc_traffic.json > $out/pmc_hbm_traffic.txt
 # the un-profiled line (never compare a profiled run with an un-profiled one)
-python bench.py --layer-report $out/layers.txt > $out/bench.json.log 2>&1
+python bench.py --steps 250 --warmup 10 --layer-report $out/layers.txt > $out/bench.json.log 2>&1
 tail -1 $out/bench.json.log
 head -12 $out/kernel_trace_summary.txt
 tail -3 $out/pmc_hbm_traffic.txt
