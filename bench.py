@@ -47,7 +47,7 @@ GFLOP_PER_FRAME = 10.779365376              # 5 389 682 688 MAC x 2 (SURVEY Appe
 CONV_LAUNCHES_PER_FRAME_CHUNK = 54           # stem + 53 tower convs, per chunk
 PEAK_BF16_TFLOPS = 2500.0                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
-BF16_SCORE_RTOL = 5e-3                      # the bf16 mode's stated tolerance (tests/test_gpu_assess.py)
+BF16_SCORE_RTOL = 4e-3                      # the bf16 mode's stated tolerance (tests/test_gpu_assess.py)
 DQN_GFLOP_PER_STEP = 10.5                    # 3 forwards + backward at B=128, T=25
 
 
@@ -392,8 +392,8 @@ def cpu_baseline_dqn():
     from oracle.torch_cpu_baseline import TorchDQN
     tr = synth.replay_transitions(n=2000, T=25, seed=2019)
     best = None
-    for threads in sorted({min(8, os.cpu_count() or 1), min(32, os.cpu_count() or 1), os.cpu_count() or 1}):
-        # the step is ~1000 tiny ops: it stops scaling after a few threads, so several counts are tried and the best is reported
+    for threads in sorted({min(8, os.cpu_count() or 1), min(16, os.cpu_count() or 1), min(32, os.cpu_count() or 1)}):
+        # the step is ~1000 tiny ops: it stops scaling after a few threads (and crawls at 256), so 8 / 16 / 32 are tried and the best is reported
         torch.set_num_threads(threads)
         dqn = TorchDQN(synth.brain_state_dict(0), synth.brain_state_dict(0))
         rs = np.random.RandomState(0)

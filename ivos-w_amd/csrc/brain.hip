@@ -19,6 +19,7 @@ constexpr int O_W1 = 0, O_B1 = 256, O_W2 = 384, O_B2 = 16768, O_WIH = 16896, O_W
               O_B3 = 180736, O_W4 = 180864, O_B4 = 180992;
 static_assert(O_B4 + 1 == IVOSW_BRAIN_NPARAMS, "arena layout");
 constexpr int HD = 128;
+int tune_get(const char* key, int dflt);   // capi.cpp
 
 // ---------------------------------------------------------------- small kernels
 // a1[row][j] = relu(W1[j,:].x[row] + b1[j])        (encoder_fc1 + relu, agent.py:49)
@@ -181,6 +182,117 @@ __global__ __launch_bounds__(512) void lstm_fwd_kernel(LstmFwd p) {
     }
 }
 
+// ---------------------------------------------------------------- forward recurrence, quad layout
+// The same recurrence with the work of a step laid out so that nothing but h crosses a thread: thread = (hidden unit j,
+// K-quarter q), the four threads of a unit are the four lanes of a DPP quad.  A thread keeps W_hh[g*128 + j][32q .. 32q+31]
+// for all four gates g (128 registers, like the kernel above), reads ITS quarter of h (8 ds_read_b128 instead of 32: the LDS
+// return path was the bound), runs four independent 32-long fma chains, and the quad sums the partials with DPP adds — no
+// LDS, no barrier.  Lane q then activates gate q (one exp per lane), the quad broadcasts the four activations back, and
+// every lane updates the unit's cell state, which lives in a REGISTER.  One barrier per step (h is double-buffered),
+// against two barriers + a 2 KB LDS round trip of the gates before.  Summation order: four K-quarters in k order, combined
+// as (q0 + q1) + (q2 + q3), then + the input-side term.
+struct QuadDpp {
+    template <int CTRL>
+    static __device__ __forceinline__ float mov(float v) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+    }
+};
+
+template <int R>
+__global__ __launch_bounds__(512) void lstm_fwd_quad_kernel(LstmFwd p) {
+    constexpr int HQ = 36;                                   // a K-quarter of h: 32 floats + 4 of padding (the four quarters of a
+    __shared__ __attribute__((aligned(16))) float h_s[2][R][4 * HQ];   // wave's reads fall on disjoint banks)
+    const int tid = threadIdx.x, j = tid >> 2, q = tid & 3;
+    float w[4][32];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4* wp = reinterpret_cast<const float4*>(p.whh + (size_t)(g * HD + j) * HD + 32 * q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = wp[i];
+            w[g][4 * i] = v.x; w[g][4 * i + 1] = v.y; w[g][4 * i + 2] = v.z; w[g][4 * i + 3] = v.w;
+        }
+    }
+    for (int i = tid; i < R * 4 * HQ; i += 512) (&h_s[0][0][0])[i] = 0.f;
+    __syncthreads();
+    const float gk = (q == 2) ? 2.0f : 1.0f;                  // tanh(x) = 2*sigmoid(2x) - 1: one branch-free exp path for all gates
+    const int Nk = p.N - p.keep_from;
+    const int row0 = blockIdx.x * R;
+    int dd[R], nn[R];
+    bool ok[R], keep[R];
+    float c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        ok[r] = row < 2 * p.N;
+        const int rc = ok[r] ? row : 2 * p.N - 1;
+        dd[r] = rc / p.N;
+        nn[r] = rc - dd[r] * p.N;
+        keep[r] = ok[r] && p.gates && nn[r] >= p.keep_from;
+        c[r] = 0.f;
+    }
+    float a_nx[R];
+    auto gx_fetch = [&](int s) {                              // lane q fetches the input-side term of gate q
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = dd[r] ? p.T - 1 - s : s;
+            a_nx[r] = p.gx[((size_t)nn[r] * p.T + t) * 512 + q * HD + j];
+        }
+    };
+    gx_fetch(0);
+    for (int s = 0; s < p.T; ++s) {
+        const int cur = s & 1;
+        float a_cur[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a_cur[r] = a_nx[r];
+        if (s + 1 < p.T) gx_fetch(s + 1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = dd[r] ? p.T - 1 - s : s;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const float* hq = &h_s[cur][r][q * HQ];
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 h4 = *reinterpret_cast<const float4*>(hq + 4 * kc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[g] = fmaf(h4.x, w[g][4 * kc], acc[g]);
+                    acc[g] = fmaf(h4.y, w[g][4 * kc + 1], acc[g]);
+                    acc[g] = fmaf(h4.z, w[g][4 * kc + 2], acc[g]);
+                    acc[g] = fmaf(h4.w, w[g][4 * kc + 3], acc[g]);
+                }
+            }
+            // quad all-reduce of the four partial sums (lanes q ^ 1, then q ^ 2): every lane ends with the same four totals
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[g] += QuadDpp::mov<0xB1>(acc[g]);         // quad_perm [1,0,3,2]
+                acc[g] += QuadDpp::mov<0x4E>(acc[g]);         // quad_perm [2,3,0,1]
+            }
+            const float mine = q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3];
+            const float pre = mine + a_cur[r];
+            const float sg = 1.0f / (1.0f + expf(-gk * pre));
+            const float act = fmaf(sg, gk, 1.0f - gk);        // lane q: gate q (i, f, g, o) of unit j
+            const float gi = QuadDpp::mov<0x00>(act), gf = QuadDpp::mov<0x55>(act), gg = QuadDpp::mov<0xAA>(act), go = QuadDpp::mov<0xFF>(act);
+            const float cn = fmaf(gf, c[r], gi * gg);
+            const float h = go * tanhf_(cn);
+            c[r] = cn;
+            if (ok[r]) {
+                if (q == 0) {
+                    h_s[cur ^ 1][r][(j >> 5) * HQ + (j & 31)] = h;
+                    p.hs[((size_t)nn[r] * p.T + t) * 256 + dd[r] * HD + j] = h;
+                }
+                if (keep[r]) {
+                    const size_t base = ((size_t)dd[r] * Nk + (nn[r] - p.keep_from)) * p.T + t;
+                    p.gates[base * 512 + q * HD + j] = act;
+                    if (q == 1) p.hprev[base * HD + j] = h_s[cur][r][(j >> 5) * HQ + (j & 31)];   // h before this frame
+                    if (q == 2) p.cs[base * HD + j] = cn;
+                }
+            }
+        }
+        __syncthreads();                                      // h of step s+1 is complete; buffer `cur` is free for step s+2
+    }
+}
+
 // ---------------------------------------------------------------- backward recurrence (BPTT)
 struct LstmBwd {
     const float* whh;    // [512,128]
@@ -281,6 +393,114 @@ __global__ __launch_bounds__(512) void lstm_bwd_kernel(LstmBwd p) {
     }
 }
 
+// ---------------------------------------------------------------- backward recurrence, quad layout
+// Thread = (hidden unit k, gate q); the four threads of a unit are a DPP quad.  Lane q computes dL/d(pre-activation) of
+// gate q of unit k (the kernel above leaves that to 128 of its 512 threads, each behind a chain of global loads), keeps
+// W_hh[q*128 + j][k] (j = 0..127) in registers, and the quad sums the four gates' contributions to dL/dh_prev[k] with DPP
+// adds: one barrier per step (the gate gradients are double-buffered in LDS), no partial-sum round trip.  The
+// activations of step s-1 are requested before the matvec of step s.  Same arithmetic per element as lstm_bwd_kernel;
+// the 512-long dot product is summed as four interleaved 32-long chains per gate, gates combined (i + f) + (g + o).
+template <int R>
+__global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(LstmBwd p) {
+    constexpr int GQ = HD + 4;                               // one gate's 128 gradients + 4 floats of padding (bank spread)
+    __shared__ __attribute__((aligned(16))) float dp_s[2][R][4 * GQ];
+    const int tid = threadIdx.x, k = tid >> 2, q = tid & 3;
+    float w[HD];
+#pragma unroll
+    for (int j = 0; j < HD; ++j) w[j] = p.whh[(size_t)(q * HD + j) * HD + k];
+    int dn[R], nn[R], s0[R];
+    bool ok[R];
+    int smax = -1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = blockIdx.x * R + r;
+        ok[r] = row < 2 * p.N;
+        dn[r] = ok[r] ? row / p.N : 0;
+        nn[r] = ok[r] ? row % p.N : 0;
+        int a = ok[r] ? (int)p.action[nn[r]] : 0;
+        a = min(max(a, 0), p.T - 1);
+        s0[r] = ok[r] ? (dn[r] ? p.T - 1 - a : a) : -1;      // step at which frame `action` is consumed
+        smax = max(smax, s0[r]);
+    }
+    // steps after the loss frame carry no gradient
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!ok[r]) continue;
+        for (int s = s0[r] + 1; s < p.T; ++s) {
+            const int t = dn[r] ? p.T - 1 - s : s;
+            p.dG[(((size_t)dn[r] * p.N + nn[r]) * p.T + t) * 512 + q * HD + k] = 0.f;
+        }
+    }
+    auto rt_of = [&](int r, int s) {                          // (direction, sample, frame) row of the kept activations at step s
+        const int sc = min(max(s, 0), p.T - 1);
+        const int t = dn[r] ? p.T - 1 - sc : sc;
+        return ((size_t)dn[r] * p.N + nn[r]) * p.T + t;
+    };
+    float dh_rec[R], dc[R], g_cur[R], c_cur[R], c_prv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        dh_rec[r] = 0.f; dc[r] = 0.f;
+        g_cur[r] = p.gates[rt_of(r, smax) * 512 + q * HD + k];
+        c_cur[r] = p.cs[rt_of(r, smax) * HD + k];
+        c_prv[r] = p.cs[rt_of(r, smax - 1) * HD + k];
+    }
+    for (int s = smax; s >= 0; --s) {
+        const int buf = s & 1;
+        float g_nx[R], c_nx[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {                          // step s-1's gate and step s-2's cell state: in flight under this step
+            g_nx[r] = p.gates[rt_of(r, s - 1) * 512 + q * HD + k];
+            c_nx[r] = p.cs[rt_of(r, s - 2) * HD + k];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool act = ok[r] && s <= s0[r];
+            const float gq = g_cur[r];
+            const float gi = QuadDpp::mov<0x00>(gq), gf = QuadDpp::mov<0x55>(gq), gg = QuadDpp::mov<0xAA>(gq), go = QuadDpp::mov<0xFF>(gq);
+            const float cc = c_cur[r];
+            const float cprev = (s > 0) ? c_prv[r] : 0.f;
+            float dh = dh_rec[r];
+            if (s == s0[r]) dh += p.dhc[(size_t)nn[r] * 256 + dn[r] * HD + k];
+            const float tc = tanhf_(cc);
+            const float dcn = fmaf(dh * go, 1.f - tc * tc, dc[r]);
+            const float di = dcn * gg * gi * (1.f - gi);
+            const float df = dcn * cprev * gf * (1.f - gf);
+            const float dg = dcn * gi * (1.f - gg * gg);
+            const float dO = dh * tc * go * (1.f - go);
+            float mine = q == 0 ? di : q == 1 ? df : q == 2 ? dg : dO;
+            mine = act ? mine : 0.f;
+            if (act) {
+                dc[r] = dcn * gf;
+                p.dG[rt_of(r, s) * 512 + q * HD + k] = mine;
+            }
+            dp_s[buf][r][q * GQ + k] = mine;
+        }
+        __syncthreads();                                       // gate gradients of step s complete; buffer buf^1 (step s+1) is free
+        if (s > 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const float* dq = &dp_s[buf][r][q * GQ];
+#pragma unroll
+                for (int jc = 0; jc < HD / 4; ++jc) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(dq + 4 * jc);
+                    a0 = fmaf(d4.x, w[4 * jc], a0);
+                    a1 = fmaf(d4.y, w[4 * jc + 1], a1);
+                    a2 = fmaf(d4.z, w[4 * jc + 2], a2);
+                    a3 = fmaf(d4.w, w[4 * jc + 3], a3);
+                    if ((jc & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keeps hipcc from hoisting all 32 reads (128 registers) at once
+                }
+                float a = (a0 + a1) + (a2 + a3);
+                a += QuadDpp::mov<0xB1>(a);
+                a += QuadDpp::mov<0x4E>(a);
+                dh_rec[r] = a;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { g_cur[r] = g_nx[r]; c_cur[r] = c_prv[r]; c_prv[r] = c_nx[r]; }
+    }
+}
+
 // ---------------------------------------------------------------- forward driver
 struct FwdBufs {
     float *a1, *e, *gx, *hs, *d1, *q;
@@ -342,7 +562,11 @@ static void brain_forward_internal(const float* prm, const float* x, int N, int 
     lf.gates = b.gates; lf.cs = b.cs; lf.hprev = b.hprev;
     const int R = rows_per_wg(2 * N);
     const int nwg = (2 * N + R - 1) / R;
-    if (R == 1) hipLaunchKernelGGL(lstm_fwd_kernel<1>, dim3(nwg), dim3(512), 0, st, lf);
+    if (tune_get("LSTM_QUAD", 1)) {
+        if (R == 1) hipLaunchKernelGGL(lstm_fwd_quad_kernel<1>, dim3(nwg), dim3(512), 0, st, lf);
+        else if (R == 2) hipLaunchKernelGGL(lstm_fwd_quad_kernel<2>, dim3(nwg), dim3(512), 0, st, lf);
+        else hipLaunchKernelGGL(lstm_fwd_quad_kernel<4>, dim3(nwg), dim3(512), 0, st, lf);
+    } else if (R == 1) hipLaunchKernelGGL(lstm_fwd_kernel<1>, dim3(nwg), dim3(512), 0, st, lf);
     else if (R == 2) hipLaunchKernelGGL(lstm_fwd_kernel<2>, dim3(nwg), dim3(512), 0, st, lf);
     else hipLaunchKernelGGL(lstm_fwd_kernel<4>, dim3(nwg), dim3(512), 0, st, lf);
     // d1 = relu(relu(hcat) * W3^T + b3)
@@ -597,7 +821,11 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     {
         const int R = rows_per_wg(2 * B);
         const int nwg = (2 * B + R - 1) / R;
-        if (R == 1) hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3(nwg), dim3(512), 0, st, lb);
+        if (tune_get("LSTM_QUAD", 1)) {
+            // one row per workgroup whatever the batch: with two or more rows the per-row state no longer fits beside W_hh
+            // (hipcc spills 320+ registers), and a second round of workgroups costs what the second row would
+            hipLaunchKernelGGL(lstm_bwd_quad_kernel<1>, dim3(2 * B), dim3(512), 0, st, lb);
+        } else if (R == 1) hipLaunchKernelGGL(lstm_bwd_kernel<1>, dim3(nwg), dim3(512), 0, st, lb);
         else if (R == 2) hipLaunchKernelGGL(lstm_bwd_kernel<2>, dim3(nwg), dim3(512), 0, st, lb);
         else hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3(nwg), dim3(512), 0, st, lb);
     }

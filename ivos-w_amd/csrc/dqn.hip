@@ -80,6 +80,18 @@ __global__ void quality_state_kernel(const float* __restrict__ scores, int n_obj
 // Adam's step counter and bias corrections kept ON the device, so that a captured HIP graph of the DQN step replays
 // correctly: tick advances step, evaluates beta1^t / beta2^t in float64 and publishes step_size / sqrt(bc2).
 // Layout (32 bytes): the step counter is the int32 at byte 16; a caller resumes from host step k by writing k there.
+// beta^step by squaring: multiplications only, so the host (ivosw_clamp_adam) and the device (adam_tick_kernel) get the same
+// float64 bits — libm's pow and the device's differ in the last place now and then, which moved step_size by a float ulp
+__host__ __device__ inline double ipow(double b, int n) {
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r *= b;
+        b *= b;
+        n >>= 1;
+    }
+    return r;
+}
+
 struct AdamDevState {
     double b1t, b2t;
     int step;
@@ -90,8 +102,8 @@ __global__ void adam_tick_kernel(AdamDevState* st, float lr, float beta1, float 
     AdamDevState s = *st;
     s.step += 1;
     // the same float64 expressions ivosw_clamp_adam evaluates on the host from its `step` argument
-    s.b1t = pow((double)beta1, (double)s.step);
-    s.b2t = pow((double)beta2, (double)s.step);
+    s.b1t = ipow((double)beta1, s.step);
+    s.b2t = ipow((double)beta2, s.step);
     s.step_size = (float)((double)lr / (1.0 - s.b1t));
     s.bc2_sqrt = (float)sqrt(1.0 - s.b2t);
     *st = s;
@@ -152,8 +164,8 @@ extern "C" int ivosw_clamp_adam(float* params, const float* grads, float* exp_av
     IVOSW_REQUIRE(params && grads && exp_avg && exp_avg_sq, "null pointer");
     IVOSW_ON_DEVICE_OF(params);
     IVOSW_REQUIRE(n > 0 && step >= 1, "n must be positive and step >= 1");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - ipow((double)beta1, step);
+    const double bc2 = 1.0 - ipow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(clamp_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), params, grads, exp_avg,

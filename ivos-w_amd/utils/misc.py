@@ -1,7 +1,7 @@
 """Seed / meter / checkpoint helpers with the reference's names and behaviour (utils/misc.py:11-115).
 
-``sequence_metric`` (J&F through davisinteractive, :118-162) is outside the hot path and needs the third-party
-``davisinteractive`` package; it is forwarded when that package is installed and raises ImportError otherwise.
+``sequence_metric`` (:118-162) keeps the reference's signature; its J / F measures run on the device
+(``ivos_w_amd.metrics`` -> ``ivosw_jf_counts``) instead of the third-party ``davisinteractive`` package.
 """
 import os
 import random
