@@ -75,6 +75,68 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     }
 }
 
+// The same reduction for up to two matrices in one launch (blockIdx.y = which), each optionally with two weighted sums on top:
+// out[n] = sum_m A[m][n]; outw[n*2 + c] = sum_m A[m][n] * x[m*2 + c] (c = 0, 1) — encoder_fc1's weight gradient
+// dW1[j][c] = sum_rows da1[row][j] * x[row][c] is a weighted column sum of the matrix whose plain column sum is db1.
+struct ColsumJob {
+    const float* A;
+    const float* x;      // [M,2] or nullptr
+    float* out;          // [N]            (split over blockIdx.z: slab z at out + z * N; the caller reduces the slabs)
+    float* outw;         // [N,2] when x   (slab z at outw + z * 2N)
+    int M, N, ld;
+};
+struct ColsumGroup { ColsumJob j[2]; };
+__global__ __launch_bounds__(1024) void colsum_group_kernel(ColsumGroup grp) {
+    __shared__ float red[3][32][33];
+    const ColsumJob& jb = grp.j[blockIdx.y];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
+    if (blockIdx.x * 32 >= jb.N) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool wx = jb.x != nullptr;
+    // rows [mbeg, mend) of this split (multiples of 32 rows, so every row group sees whole strides)
+    const int per = ((jb.M + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;
+    const int mbeg = blockIdx.z * per, mend = min(jb.M, mbeg + per);
+    if (n < jb.N) {
+        int m = mbeg + rg;
+        for (; m + 224 < mend; m += 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = jb.A[(size_t)(m + 32 * u) * jb.ld + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u & 3] += v[u];
+            if (wx) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float2 xv = *reinterpret_cast<const float2*>(jb.x + (size_t)(m + 32 * u) * 2);
+                    s0[u & 3] = fmaf(v[u], xv.x, s0[u & 3]);
+                    s1[u & 3] = fmaf(v[u], xv.y, s1[u & 3]);
+                }
+            }
+        }
+        for (; m < mend; m += 32) {
+            const float v = jb.A[(size_t)m * jb.ld + n];
+            s[0] += v;
+            if (wx) {
+                const float2 xv = *reinterpret_cast<const float2*>(jb.x + (size_t)m * 2);
+                s0[0] = fmaf(v, xv.x, s0[0]);
+                s1[0] = fmaf(v, xv.y, s1[0]);
+            }
+        }
+    }
+    red[0][rg][c] = (s[0] + s[1]) + (s[2] + s[3]);
+    red[1][rg][c] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+    red[2][rg][c] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+    __syncthreads();
+    if (rg < 3 && n < jb.N && (rg == 0 || wx)) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[rg][i][c];
+        if (rg == 0) jb.out[(size_t)blockIdx.z * jb.N + n] = t;
+        else jb.outw[(size_t)blockIdx.z * 2 * jb.N + n * 2 + (rg - 1)] = t;
+    }
+}
+
 __global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = a[i] + b[i];
@@ -685,8 +747,8 @@ static size_t dqn_ws_floats(int B, int T) {
     n += 2 * r * 2;                        // xcat
     n += B + (size_t)B * 128 * 2 + (size_t)B * 256 * 2;  // dq, dd1c, w4term, hcc, dhc
     n += 2 * r * 512 + r * 512 + r * 128 + r * 128;       // dG, dgx, de, da1
-    n += 2 * (size_t)WG_SPLIT * 512 * 128; // split-K slabs, one set per stream
-    return n + 64 * 32;
+    n += 3 * (size_t)WG_SPLIT * 512 * 128; // split-K slabs: one set per concurrently reduced weight gradient
+    return n + 8 * 512 + 64 * 32;
 }
 
 }  // namespace ivosw
@@ -771,6 +833,8 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     w.da1 = ar.take<float>((size_t)rows * 128);
     w.slabs = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
     float* slabs2 = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
+    float* slabs3 = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
+    float* slabs4 = ar.take<float>(8 * 512);                  // row-split column sums
 
     // The step is a chain of ~40 launches that each occupy a fraction of the chip for 5-30 us: independent branches run
     // on a second stream (fork / join with events), so their kernels overlap instead of queueing behind each other.
@@ -829,58 +893,94 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         else if (R == 2) hipLaunchKernelGGL(lstm_bwd_kernel<2>, dim3(nwg), dim3(512), 0, st, lb);
         else hipLaunchKernelGGL(lstm_bwd_kernel<4>, dim3(nwg), dim3(512), 0, st, lb);
     }
-    // dgx = dG[fw] + dG[bw]  (the same e_t feeds both directions)
-    {
-        const size_t n = (size_t)rows * 512;
-        hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.dG, w.dG + n, w.dgx, n);
-    }
     const float* e_s = w.pol.e + (size_t)rows * 128;
     const float* a1_s = w.pol.a1 + (size_t)rows * 128;
+    const float* dG_bw = w.dG + (size_t)rows * 512;            // dgx = dG[fw] + dG[bw] (the same e_t feeds both directions): summed
+                                                                // on load by the two GEMMs that consume it (GemmF32::A2)
+    if (!tune_get("DQN_GROUP", 1)) {
+        const size_t n = (size_t)rows * 512;
+        hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.dG, dG_bw, w.dgx, n);
+    }
+    const bool grp = tune_get("DQN_GROUP", 1) != 0;
+    const float* dgx_a = grp ? w.dG : w.dgx;
+    const float* dgx_a2 = grp ? dG_bw : nullptr;
 
-    // ONE fork (every cross-stream event costs 7-13 us of stream time): the side stream takes the weight gradients whose
-    // operands exist by now (decoder, W_hh, W_ih: ~75 us), the main stream the dgrad chain down to the encoder (~100 us)
-    fork(2);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.w4term, B, 128, 128, grads + O_W4);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.dd1c, B, 128, 128, grads + O_B3);
+    GemmF32 gw[4];
     // dW3[128,256] = dd1c^T * hcc
-    g = GemmF32{};
-    g.A = w.dd1c; g.sam = 1; g.sak = 128; g.B = w.hcc; g.sbk = 256; g.sbn = 1; g.C = grads + O_W3; g.ldc = 256;
-    g.M = 128; g.N = 256; g.K = B; g.splitk = 1;
-    launch_gemm_f32(g, s2);
-    // dWhh[512,128] = sum_{d,n,t} dG^T * hprev          (K = 2*B*T)
-    g = GemmF32{};
-    g.A = w.dG; g.sam = 1; g.sak = 512; g.B = w.pol.hprev; g.sbk = 128; g.sbn = 1; g.ldc = 128;
-    g.M = 512; g.N = 128; g.K = 2 * rows;
-    launch_gemm_f32_splitk(g, grads + O_WHH, slabs2, WG_SPLIT, s2);
+    gw[0] = GemmF32{};
+    gw[0].A = w.dd1c; gw[0].sam = 1; gw[0].sak = 128; gw[0].B = w.hcc; gw[0].sbk = 256; gw[0].sbn = 1; gw[0].C = grads + O_W3; gw[0].ldc = 256;
+    gw[0].M = 128; gw[0].N = 256; gw[0].K = B; gw[0].splitk = 1;
+    // dWhh[512,128] = sum_{d,n,t} dG^T * hprev          (K = 2*B*T), split-K slabs
+    gw[1] = GemmF32{};
+    gw[1].A = w.dG; gw[1].sam = 1; gw[1].sak = 512; gw[1].B = w.pol.hprev; gw[1].sbk = 128; gw[1].sbn = 1; gw[1].ldc = 128;
+    gw[1].M = 512; gw[1].N = 128; gw[1].K = 2 * rows; gw[1].C = slabs2; gw[1].splitk = WG_SPLIT;
     // dWih[512,128] = dgx^T * e
-    g = GemmF32{};
-    g.A = w.dgx; g.sam = 1; g.sak = 512; g.B = e_s; g.sbk = 128; g.sbn = 1; g.ldc = 128;
-    g.M = 512; g.N = 128; g.K = rows;
-    launch_gemm_f32_splitk(g, grads + O_WIH, slabs2, WG_SPLIT, s2);
-
+    gw[2] = GemmF32{};
+    gw[2].A = dgx_a; gw[2].A2 = dgx_a2; gw[2].sam = 1; gw[2].sak = 512; gw[2].B = e_s; gw[2].sbk = 128; gw[2].sbn = 1; gw[2].ldc = 128;
+    gw[2].M = 512; gw[2].N = 128; gw[2].K = rows; gw[2].C = slabs3; gw[2].splitk = WG_SPLIT;
     // de[rows,128] = dgx * Wih
-    g = GemmF32{};
-    g.A = w.dgx; g.sam = 512; g.sak = 1; g.B = policy + O_WIH; g.sbk = 128; g.sbn = 1; g.C = w.de; g.ldc = 128;
-    g.M = rows; g.N = 128; g.K = 512; g.splitk = 1;
-    launch_gemm_f32(g, st);
-    // dW2[128,128] = de^T * a1 ; db2 = colsum(de)
-    g = GemmF32{};
-    g.A = w.de; g.sam = 1; g.sak = 128; g.B = a1_s; g.sbk = 128; g.sbn = 1; g.ldc = 128;
-    g.M = 128; g.N = 128; g.K = rows;
-    launch_gemm_f32_splitk(g, grads + O_W2, w.slabs, WG_SPLIT, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.de, rows, 128, 128, grads + O_B2);
+    GemmF32 gde = GemmF32{};
+    gde.A = dgx_a; gde.A2 = dgx_a2; gde.sam = 512; gde.sak = 1; gde.B = policy + O_WIH; gde.sbk = 128; gde.sbn = 1; gde.C = w.de; gde.ldc = 128;
+    gde.M = rows; gde.N = 128; gde.K = 512; gde.splitk = 1;
     // da1[rows,128] = (de * W2) . (a1 > 0)
-    g = GemmF32{};
-    g.A = w.de; g.sam = 128; g.sak = 1; g.B = policy + O_W2; g.sbk = 128; g.sbn = 1; g.C = w.da1; g.ldc = 128;
-    g.M = rows; g.N = 128; g.K = 128; g.mask = a1_s; g.splitk = 1;
-    launch_gemm_f32(g, st);
-    // dW1[128,2] = da1^T * x ; db1 = colsum(da1)
-    g = GemmF32{};
-    g.A = w.da1; g.sam = 1; g.sak = 128; g.B = state; g.sbk = 2; g.sbn = 1; g.ldc = 2;
-    g.M = 128; g.N = 2; g.K = rows;
-    launch_gemm_f32_splitk(g, grads + O_W1, w.slabs, WG_SPLIT, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.da1, rows, 128, 128, grads + O_B1);
-    join(3);
+    GemmF32 ga = GemmF32{};
+    ga.A = w.de; ga.sam = 128; ga.sak = 1; ga.B = policy + O_W2; ga.sbk = 128; ga.sbn = 1; ga.C = w.da1; ga.ldc = 128;
+    ga.M = rows; ga.N = 128; ga.K = 128; ga.mask = a1_s; ga.splitk = 1;
+    // dW2[128,128] = de^T * a1 ; db2 = colsum(de)
+    GemmF32 gb = GemmF32{};
+    gb.A = w.de; gb.sam = 1; gb.sak = 128; gb.B = a1_s; gb.sbk = 128; gb.sbn = 1; gb.ldc = 128;
+    gb.M = 128; gb.N = 128; gb.K = rows;
+    if (grp) {
+        // Everything after the recurrence on ONE stream, as four launches (a fork / join pair costs ~20 us of stream time and
+        // the side stream's GEMMs took the CUs of the chain that everything else waits for):
+        //   1. {de (first in the grid: the chain below depends on it), dW3, dWhh slabs, dWih slabs}
+        //   2. {da1, dW2 slabs}: both read de and nothing of each other
+        //   3. column sums {dW4 <- w4term, db3 <- dd1c} and, split 8 ways over the rows, {db2 <- de} {db1, dW1 <- da1 weighted by x}
+        //   4. one fixed-order reduction of every slab set
+        GemmF32 g1[4] = {gde, gw[0], gw[1], gw[2]};
+        launch_gemm_f32_group(g1, 4, st);
+        gb.C = w.slabs; gb.splitk = WG_SPLIT;
+        GemmF32 g2[2] = {ga, gb};
+        launch_gemm_f32_group(g2, 2, st);
+        constexpr int CS = 8;                           // row splits of the two long column sums
+        float* cs_b2 = slabs4;                          // [CS][128]
+        float* cs_b1 = slabs4 + CS * 128;               // [CS][128]
+        float* cs_w1 = slabs4 + 2 * CS * 128;           // [CS][256]
+        ColsumGroup c0{};
+        c0.j[0] = ColsumJob{w.w4term, nullptr, grads + O_W4, nullptr, B, 128, 128};
+        c0.j[1] = ColsumJob{w.dd1c, nullptr, grads + O_B3, nullptr, B, 128, 128};
+        hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 2, 1), dim3(1024), 0, st, c0);
+        ColsumGroup c1{};
+        c1.j[0] = ColsumJob{w.de, nullptr, cs_b2, nullptr, rows, 128, 128};
+        c1.j[1] = ColsumJob{w.da1, state, cs_b1, cs_w1, rows, 128, 128};
+        hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 2, CS), dim3(1024), 0, st, c1);
+        ReduceGroup rg{};
+        rg.slabs[0] = slabs2; rg.out[0] = grads + O_WHH; rg.n[0] = 512 * 128; rg.nslab[0] = WG_SPLIT;
+        rg.slabs[1] = slabs3; rg.out[1] = grads + O_WIH; rg.n[1] = 512 * 128; rg.nslab[1] = WG_SPLIT;
+        rg.slabs[2] = w.slabs; rg.out[2] = grads + O_W2; rg.n[2] = 128 * 128; rg.nslab[2] = WG_SPLIT;
+        rg.slabs[3] = cs_b2; rg.out[3] = grads + O_B2; rg.n[3] = 128; rg.nslab[3] = CS;
+        rg.slabs[4] = cs_b1; rg.out[4] = grads + O_B1; rg.n[4] = 128; rg.nslab[4] = CS;
+        rg.slabs[5] = cs_w1; rg.out[5] = grads + O_W1; rg.n[5] = 256; rg.nslab[5] = CS;
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(512 * 128 / 256, 6), dim3(256), 0, st, rg);
+    } else {
+        fork(2);
+        hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.w4term, B, 128, 128, grads + O_W4);
+        hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.dd1c, B, 128, 128, grads + O_B3);
+        launch_gemm_f32(gw[0], s2);
+        launch_gemm_f32_splitk(gw[1], grads + O_WHH, slabs2, WG_SPLIT, s2);
+        launch_gemm_f32_splitk(gw[2], grads + O_WIH, slabs2, WG_SPLIT, s2);
+        launch_gemm_f32(gde, st);
+        launch_gemm_f32_splitk(gb, grads + O_W2, w.slabs, WG_SPLIT, st);
+        hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.de, rows, 128, 128, grads + O_B2);
+        launch_gemm_f32(ga, st);
+        // dW1[128,2] = da1^T * x ; db1 = colsum(da1)
+        g = GemmF32{};
+        g.A = w.da1; g.sam = 1; g.sak = 128; g.B = state; g.sbk = 2; g.sbn = 1; g.ldc = 2;
+        g.M = 128; g.N = 2; g.K = rows;
+        launch_gemm_f32_splitk(g, grads + O_W1, w.slabs, WG_SPLIT, st);
+        hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.da1, rows, 128, 128, grads + O_B1);
+        join(3);
+    }
     if (!sync_ok) {
         (void)hipGetLastError();
         set_error("ivosw_dqn_loss_grad: a fork/join event between the two streams failed");

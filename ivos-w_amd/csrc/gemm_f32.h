@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmF32 {
     const float* A;   // A(m,k) = A[m*sam + k*sak]
+    const float* A2;  // optional: A(m,k) += A2[m*sam + k*sak] on load (dgx = dG[fw] + dG[bw] without a pass of its own)
     const float* B;   // B(k,n) = B[k*sbk + n*sbn]
     float* C;         // C[m*ldc + n]   (split-K: slab z at C + z*M*ldc)
     int M, N, K;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 g) {
             if (a_kfast) { k = tid % GB_K; m = tid / GB_K + (256 / GB_K) * i; } else { m = tid & 63; k = (tid >> 6) + 4 * i; }
             const int gm = m0 + m, gk = k0 + k;
             float v = 0.f;
-            if (gm < g.M && gk < kend) v = g.A[gm * g.sam + gk * g.sak];
+            if (gm < g.M && gk < kend) { v = g.A[gm * g.sam + gk * g.sak]; if (g.A2) v += g.A2[gm * g.sam + gk * g.sak]; }
             ra[i] = g.relu_a ? fmaxf(v, 0.f) : v;
             int n, kb;
             if (b_kfast) { kb = tid % GB_K; n = tid / GB_K + (256 / GB_K) * i; } else { n = tid & 63; kb = (tid >> 6) + 4 * i; }
@@ -110,14 +111,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32 g) {
 // == 1), 16-byte aligned and its extents are multiples of 4, a thread fetches 4 float4 per operand and K-step instead
 // of 16 scalars (each with its own 64-bit address arithmetic) — the scalar kernel spends 3.6 us per K-step against
 // 1 us of MFMA issue.  Operand modes are uniform per launch (amode / bmode: 0 = contiguous along K, 1 = along M / N).
-__global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32 g, int amode, int bmode) {
-    __shared__ float As[GB_K][G_LD];
-    __shared__ float Bs[GB_K][G_LD];
+__device__ __forceinline__ void gemm_vec_tile(const GemmF32& g, int amode, int bmode, int bx, int by, int bz, float (*As)[G_LD], float (*Bs)[G_LD]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    const int m0 = by * GB_M, n0 = bx * GB_N;
     const int kchunk = (((g.K + g.splitk - 1) / g.splitk) + GB_K - 1) / GB_K * GB_K;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = bz * kchunk;
     const int kend = min(g.K, kbeg + kchunk);
     const int q16 = tid & 15, q4 = tid >> 4;      // float4 slot: 16 per 64-float line, lines q4 + 16 i
 
@@ -141,7 +140,14 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32 g, int amode,
             const bool ka = amode == 0 ? (k0 + 4 * q16 < kend) : (k0 + line < kend);
             const bool kb = bmode == 0 ? (k0 + 4 * q16 < kend) : (k0 + line < kend);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = v;
-            if (aok[i] && ka) v = *reinterpret_cast<const float4*>(ap[i] + (amode == 0 ? (size_t)k0 : (size_t)k0 * g.sak));
+            if (aok[i] && ka) {
+                const size_t ko = amode == 0 ? (size_t)k0 : (size_t)k0 * g.sak;
+                v = *reinterpret_cast<const float4*>(ap[i] + ko);
+                if (g.A2) {
+                    const float4 v2 = *reinterpret_cast<const float4*>(g.A2 + (ap[i] - g.A) + ko);
+                    v = make_float4(v.x + v2.x, v.y + v2.y, v.z + v2.z, v.w + v2.w);
+                }
+            }
             if (bok[i] && kb) u = *reinterpret_cast<const float4*>(bp[i] + (bmode == 0 ? (size_t)k0 : (size_t)k0 * g.sbk));
             if (g.relu_a) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
             ra[i] = v;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32 g, int amode,
             }
         }
     }
-    float* C = g.C + (size_t)blockIdx.z * g.M * g.ldc;
+    float* C = g.C + (size_t)bz * g.M * g.ldc;
     const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -194,6 +200,34 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32 g, int amode,
     }
 }
 
+__global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32 g, int amode, int bmode) {
+    __shared__ float As[GB_K][G_LD];
+    __shared__ float Bs[GB_K][G_LD];
+    gemm_vec_tile(g, amode, bmode, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Several independent GEMMs in ONE launch (the weight gradients of a DQN step: each is a few dozen tiles, far too small to
+// fill the chip alone, and each launch boundary costs as much as the GEMM): workgroup -> (problem, tile) by a prefix table.
+constexpr int GROUP_MAX = 6;
+struct GemmGroup {
+    GemmF32 g[GROUP_MAX];
+    int amode[GROUP_MAX], bmode[GROUP_MAX];
+    int first[GROUP_MAX + 1];          // first workgroup of problem i; first[n] = grid size
+    int n;
+};
+__global__ __launch_bounds__(256) void gemm_f32_group_kernel(GemmGroup grp) {
+    __shared__ float As[GB_K][G_LD];
+    __shared__ float Bs[GB_K][G_LD];
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+        if (i < grp.n && (int)blockIdx.x >= grp.first[i]) p = i;
+    const GemmF32& g = grp.g[p];
+    const int local = blockIdx.x - grp.first[p];
+    const int nx = (g.N + GB_N - 1) / GB_N, ny = (g.M + GB_M - 1) / GB_M;
+    gemm_vec_tile(g, grp.amode[p], grp.bmode[p], local % nx, (local / nx) % ny, local / (nx * ny), As, Bs);
+}
+
 // out[i] = sum_z slabs[z*n + i], fixed order.
 __global__ void splitk_reduce_kernel(const float* slabs, float* out, int n, int nslab) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,6 +235,22 @@ __global__ void splitk_reduce_kernel(const float* slabs, float* out, int n, int 
     float s = 0.f;
     for (int z = 0; z < nslab; ++z) s += slabs[(size_t)z * n + i];
     out[i] = s;
+}
+
+// the same for up to six slab sets in one launch (blockIdx.y = which)
+constexpr int REDUCE_MAX = 6;
+struct ReduceGroup {
+    const float* slabs[REDUCE_MAX];
+    float* out[REDUCE_MAX];
+    int n[REDUCE_MAX], nslab[REDUCE_MAX];
+};
+__global__ void splitk_reduce_group_kernel(ReduceGroup r) {
+    const int w = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r.n[w]) return;
+    const float* sl = r.slabs[w];
+    float s = 0.f;
+    for (int z = 0; z < r.nslab[w]; ++z) s += sl[(size_t)z * r.n[w] + i];
+    r.out[w][i] = s;
 }
 
 // operand mode for the 16-byte path: 0 = contiguous along K, 1 = contiguous along the M / N extent, -1 = not eligible
@@ -215,7 +265,8 @@ inline void launch_gemm_f32(const GemmF32& g, hipStream_t st) {
     dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M, g.splitk);
     const int am = gemm_vec_mode(g.A, g.sam, g.sak, g.M, g.K), bm = gemm_vec_mode(g.B, g.sbn, g.sbk, g.N, g.K);
     static const bool vec_off = getenv("IVOSW_GEMM_SCALAR") != nullptr;
-    if (am >= 0 && bm >= 0 && !vec_off) hipLaunchKernelGGL(gemm_f32_vec_kernel, grid, dim3(256), 0, st, g, am, bm);
+    const bool a2ok = !g.A2 || (reinterpret_cast<uintptr_t>(g.A2) & 15) == 0;
+    if (am >= 0 && bm >= 0 && a2ok && !vec_off) hipLaunchKernelGGL(gemm_f32_vec_kernel, grid, dim3(256), 0, st, g, am, bm);
     else hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
 }
 
@@ -226,6 +277,27 @@ inline void launch_gemm_f32_splitk(GemmF32 g, float* out, float* slabs, int nspl
     launch_gemm_f32(g, st);
     const int n = g.M * g.ldc;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, slabs, out, n, nsplit);
+}
+
+// n GEMMs (every one eligible for the 16-byte path, else they are launched one by one) as one grouped launch
+inline void launch_gemm_f32_group(const GemmF32* gs, int n, hipStream_t st) {
+    GemmGroup grp{};
+    bool ok = n <= GROUP_MAX;
+    int total = 0;
+    for (int i = 0; ok && i < n; ++i) {
+        const GemmF32& g = gs[i];
+        const int am = gemm_vec_mode(g.A, g.sam, g.sak, g.M, g.K), bm = gemm_vec_mode(g.B, g.sbn, g.sbk, g.N, g.K);
+        ok = am >= 0 && bm >= 0 && (!g.A2 || (reinterpret_cast<uintptr_t>(g.A2) & 15) == 0);
+        grp.g[i] = g; grp.amode[i] = am; grp.bmode[i] = bm; grp.first[i] = total;
+        total += ((g.N + GB_N - 1) / GB_N) * ((g.M + GB_M - 1) / GB_M) * g.splitk;
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i) launch_gemm_f32(gs[i], st);
+        return;
+    }
+    grp.n = n;
+    for (int i = n; i <= GROUP_MAX; ++i) grp.first[i] = total;
+    hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(total), dim3(256), 0, st, grp);
 }
 
 }  // namespace ivosw
