@@ -164,7 +164,9 @@ def bench_assess(args, rank, world, dev, dist):
     launches = cnt.value // args.steps
     # sustained: the same measurement over >= 1 s, whatever K was
     sus = None
-    if dt < 1.0:
+    if args.min_warm_s <= 0:
+        sus = {"value": None, "note": "skipped (--min-warm-s 0: profiling run)"}
+    elif dt < 1.0:
         n = int(1.2 / (dt / args.steps)) + 1
         sdt = timed(step, n, 0, dev, dist)
         sus = {"value": round(world * args.batch * n / sdt, 1), "steps": n, "seconds": round(sdt, 3)}

@@ -54,7 +54,9 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
     constexpr int SLICE = NPX * ROWB;                // one 64-channel slice of the pixel image
     constexpr int IMG_BYTES = NSL * SLICE, STG_OFF = IMG_BYTES;
     constexpr int HP = NPT / 2;                      // pixel tiles per rolling half
-    static_assert(IMG_BYTES == 131072 && CPW * NPT == 8 && IMG_BYTES + 8 * 4096 == WIDE_LDS, "tile geometry");
+    constexpr int NACC = CPW * NPT;                  // accumulator tiles per wave: 8 (128 registers), 4 for the one-frame res5 variant
+    static_assert((IMG_BYTES == 131072 && NACC == 8) || (IMG_BYTES == 65536 && NACC == 4), "tile geometry");
+    static_assert(IMG_BYTES + 8 * 4096 <= WIDE_LDS, "LDS budget");
     static_assert(4 * SLICE <= IMG_BYTES, "x ring: 4 slots");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,10 +70,10 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
     };
     stamp(0);
     if (tid < 32) *reinterpret_cast<unsigned*>(lds + STG_OFF + tid * 4) = 0u;   // the zero row of phase B (visible after phase A's barriers)
-    f32x16 acc[8];                                   // [channel tile c of the wave][pixel tile i] at c * NPT + i
+    f32x16 acc[NACC];                                // [channel tile c of the wave][pixel tile i] at c * NPT + i
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NACC; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     };
@@ -79,8 +81,10 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
     // next k-step while the other half's MFMAs run
     u32x4 pf[NPT];
     auto rd_tiles = [&](unsigned a, int half) {      // pixel tiles half*HP .. of the image row block at `a` (tile t = +t*4096 bytes)
-        static_assert(NPT == 8 || NPT == 4, "tile offsets are immediates");
-        if (NPT == 8) {
+        static_assert(NPT == 8 || NPT == 4 || NPT == 2, "tile offsets are immediates");
+        if (NPT == 2) {
+            if (half == 0) pf[0] = lds_read_b128_o<0>(a); else pf[NPT - 1] = lds_read_b128_o<4096>(a);
+        } else if (NPT == 8) {
             if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); pf[2] = lds_read_b128_o<8192>(a); pf[3] = lds_read_b128_o<12288>(a); }
             else { pf[4] = lds_read_b128_o<16384>(a); pf[5] = lds_read_b128_o<20480>(a); pf[6] = lds_read_b128_o<24576>(a); pf[NPT - 1] = lds_read_b128_o<28672>(a); }
         } else {
@@ -332,7 +336,7 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
 #pragma unroll
             for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + (size_t)(it * 16 + prr) * CIN + (size_t)ct0 * 32 + 8 * u);
 #pragma unroll
-            for (int item = 0; item < 8; ++item) {
+            for (int item = 0; item < NACC; ++item) {
                 const int c = item / NPT, i = item % NPT;
                 const size_t cofs = (size_t)(ct0 + c) * 32 + 8 * u;
                 const f32x16& a = acc[item];
@@ -342,7 +346,7 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
                     *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
                 }
                 uint4 rn[2];
-                if (item < 7) {
+                if (item < NACC - 1) {
                     const int c1 = (item + 1) / NPT, i1 = (item + 1) % NPT;
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
@@ -361,7 +365,7 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
                         pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
                     *reinterpret_cast<uint4*>(Y + (size_t)(i * 32 + pr) * CIN + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
-                if (item < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
+                if (item < NACC - 1) { rr[0] = rn[0]; rr[1] = rn[1]; }
             }
         }
         stamp(6);
@@ -731,8 +735,15 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
 //            Wb fragment serves two MFMAs; the upper K half hands its partial sums over through LDS (fp32)
 //   phase C  wave = output-channel tile w, 4 pixel tiles; store pass as above
 // LDS: [0, 73728) ring (3 x 24 KB) -> t1 [0, 23040) -> t2 [24576, 40960) ; [40960, 73728) partial sums, then staging.
-template <bool DS>
+//
+// TIN / ND (conv1 forwarding): with TIN the workgroup does not read the 256-channel x halo (92 KB per tile) to compute t1 on
+// it; it loads the 64-channel t1 halo (23 KB) that the previous block's phase D left in HBM.  With ND > 0 the store pass also
+// parks the finished y tile in LDS (two halves of 64 pixels x 256 channels, 32 KB, over the dead t1 / t2 / x images) and phase D
+// applies the NEXT block's conv1 (256 -> ND, K = 256) to it: t1out = relu(Wd y + bd).  Per tile: 23 + 64 (residual) KB in,
+// 64 + 16 KB out instead of 92 + 64 in, 64 out; no halo recompute; and res3's first 1x1 layer (a 0.8 GB HBM pass) disappears.
+template <bool DS, bool TIN, int ND>
 __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) {
+    static_assert(!(DS && TIN) && (ND == 0 || ND == 64 || ND == 128), "variants");
     constexpr int C = 64, CIN = DS ? 64 : 256, COUT = 256, NKA = CIN / 64, HW = 64, BTY = 8, BTX = 16, HTX = 18, HR = 180, NGA = 23;
     constexpr int SLOT = 24576, T1_OFF = DS ? SLOT : 0, T2_OFF = SLOT, STG_OFF = DS ? 2 * SLOT : 40960;
     // biases wait in LDS (a global load at the head of every epilogue would expose an L2 round trip each time): behind the
@@ -1281,7 +1292,7 @@ bool bneck_wide_fusable(const BneckWideArgs& a) {
     if (!a.fa || !a.fb || !a.fc || a.Cin != 4 * a.Cmid || a.H != a.W) return false;
     // res5 (Cmid 512, 8x8 frames, two per workgroup) is instantiated and correct but NOT used: 8.7 MB of weights per
     // 128-pixel workgroup and only B/2 workgroups make it slower (240 us) than the three layer kernels (201 us)
-    if (a.Cmid == 512 && a.H == 8 && a.B % 2 == 0) return tune_get("FUSE_WIDE5", 0) != 0;
+    if (a.Cmid == 512 && a.H == 8) { const int f5 = tune_get("FUSE_WIDE5", 0); return f5 == 2 || (f5 == 1 && a.B % 2 == 0); }
     if (a.Cmid == 128 && a.H == 32) return a.zeros != nullptr && tune_get("FUSE_WIDE3", 1) != 0;
     if (a.Cmid == 64 && a.H == 64) return a.zeros != nullptr && tune_get("FUSE_WIDE2", 1) != 0;
     return a.Cmid == 256 && a.H == 16;
@@ -1298,6 +1309,7 @@ void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     else if (a.Cmid == 64 && tune_get("HALO64S", 1)) hipLaunchKernelGGL(bneck_halo64s_kernel<false>, dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64) hipLaunchKernelGGL((bneck_halo_kernel<64>), dim3(a.B * 16), dim3(512), 0, st, a);
     else if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
+    else if (tune_get("FUSE_WIDE5", 0) == 2) hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 1>), dim3(a.B), dim3(512), 0, st, a);   // one frame per workgroup
     else hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 2>), dim3(a.B / 2), dim3(512), 0, st, a);
     prof_end(tok, st);
 }

@@ -58,7 +58,12 @@ struct BneckWideArgs {
     unsigned long long* ts;            // optional [B][8] s_memtime stamps at the phase boundaries (ivosw_bneck_wide_probe)
     int ds;                            // 1: first block of res2 (Cin = Cmid = 64): fc = [conv3 | downsample] along K (K = 128), bc = bias sum
     int debug;                         // (unused by the current kernels; the ablation bits of the res2 experiments were removed
-                                       // again: ~20 branches in a kernel that is instruction-issue-bound)
+                                       // again: ~20 branches in a kernel that is instruction-issue-bound)    // conv1 forwarding (res2, tunable FWD2): a block's first 1x1 is a pointwise function of the previous block's output, so the
+    // PREVIOUS block computes it on its own tile while y is still on chip (phase D) and this block starts from t1:
+    const void* t1in;                  // NHWC [B,H,W,Cmid] = relu(bn1(conv1(x))) written by the previous block, or NULL (compute it here)
+    void* t1out;                       // NHWC [B,H,W,nd]: the NEXT block's conv1 applied to this block's output y, or NULL
+    const void* fd; const float* bd;   // that conv1 [nd][4*Cmid] in fragment order, and its bias
+    int nd;                            // 64 (next block of res2) or 128 (first block of res3)
 };
 // a run of consecutive identity blocks of one stage (res4: one frame per workgroup) in ONE launch
 struct BneckStageArgs {

@@ -43,6 +43,7 @@ class ReplayMemory:
         self.COLUMNS = list(_CSV_COLUMNS)
         self._rows, self._label0, self._memory_pd = [], 0, None      # CSV image: text rows + first index label
         self._pending, self._needs_pandas, self._parsed = 0, False, {}
+        self._col_kind = {}                        # pandas dtype of every numeric column of the image: int / float / object
         self.csv_sync_every = 1                    # 1 = rewrite memory_pool.csv on every push, like the reference
         self.seq_list = []
 
@@ -124,8 +125,54 @@ class ReplayMemory:
         t = str(v)
         return None if any(ch in t for ch in ',"\r\n') else t
 
+    _NUMERIC = ("scribble_iter", "n_interaction", "n_interaction_next", "action", "reward_step", "reward_done")
+
+    def _promote(self, col):
+        """An int64 column that meets a typed float value becomes float64 for EVERY row, past and future: "0" is rewritten as "0.0"."""
+        k = self.COLUMNS.index(col)
+        out = []
+        for r in self._rows:
+            cells = r.split(",")
+            c = cells[k]
+            if c and "." not in c and "e" not in c and "n" not in c:       # an integer literal ('nan' / 'inf' stay)
+                cells[k] = repr(float(int(c)))
+            out.append(",".join(cells))
+        self._rows = out
+        self._parsed = {}
+
     def _format_row(self, row):
-        cells = [self._fmt(row[c]) for c in self.COLUMNS]
+        """One CSV row as the reference's ``concat`` + ``to_csv`` (:139-152) would write it.  pandas types every numeric column
+        of the pool: a one-row frame built from a python / numpy SCALAR is int64 or float64, one built from a 0-d ndarray
+        (what ``agent_business`` passes for the rewards) is ``object``; concat gives int64 + float64 -> float64 (every row of
+        the column is then written as a float, past rows included, and an int pushed later too), anything + object -> object
+        (every cell keeps the text of its own type from then on)."""
+        cells = []
+        for c in self.COLUMNS:
+            v = row[c]
+            if c in self._NUMERIC and not isinstance(v, (bool, np.bool_)):
+                if isinstance(v, np.ndarray) and v.ndim == 0:
+                    kind, v = "object", v.item()
+                elif isinstance(v, (float, np.floating)):
+                    kind = "float"
+                elif isinstance(v, (int, np.integer)):
+                    kind = "int"
+                else:
+                    kind = "object"
+                have = self._col_kind.get(c) if self._rows else None
+                if have is None or have == kind:
+                    now = kind
+                elif "object" in (have, kind):
+                    now = "object"
+                else:
+                    now = "float"                                  # int64 meets float64
+                    if have == "int":
+                        self._promote(c)
+                    else:
+                        v = float(v)
+                if now == "float" and kind == "int":
+                    v = float(v)
+                self._col_kind[c] = now
+            cells.append(self._fmt(v))
         return None if any(c is None for c in cells) else ",".join(cells)
 
     def _rows_from_frame(self, frame):
@@ -146,6 +193,8 @@ class ReplayMemory:
         self._memory_pd = frame
         self._rows = self._rows_from_frame(frame) if len(frame) else []
         self._label0 = int(frame.index.min()) if len(frame) else 0
+        self._col_kind = {c: ("float" if str(frame[c].dtype).startswith("float") else "int" if str(frame[c].dtype).startswith("int") else "object")
+                          for c in self._NUMERIC if c in frame.columns}
 
     def csv_text(self):
         return "," + ",".join(self.COLUMNS) + "\n" + "".join(f"{self._label0 + i},{r}\n" for i, r in enumerate(self._rows))

@@ -167,3 +167,46 @@ def test_cells_that_need_quoting_fall_back_to_pandas(tmp_path):
         mem.push_to_csv(str(tmp_path))
         frame = _reference_push_to_csv(frame, r, 3, mem.COLUMNS)
         assert open(tmp_path / "memory_pool.csv").read() == frame.to_csv()
+
+
+def _push_sequence_against_pandas(tmp_path, values, cap=4, preload=None):
+    """The reference's push_to_csv (models/momory_pool.py:126-153) is a pandas concat + to_csv: replay it with pandas itself and
+    compare the file after every push."""
+    import pandas as pd
+    from ivos_w_amd.models.momory_pool import ReplayMemory
+    d = str(tmp_path)
+    m = ReplayMemory(cap)
+    ref = None
+    cols = m.COLUMNS
+    if preload is not None:
+        p = os.path.join(d, "pre.csv")
+        open(p, "w").write(preload)
+        m.load_from_csv(p, d, 0)
+        ref = pd.read_csv(os.path.join(d, "memory_pool.csv"), index_col=0)
+        cap = m.capacity
+    for i, rd in enumerate(values):
+        st = dict(sequence="s", scribble_iter=1, n_interaction=i + 1)
+        ns = dict(sequence="s", scribble_iter=1, n_interaction=i + 2)
+        m.push(st, 3, ns, np.array(1), rd, False, "0.1/0.2", "0.2/0.3", "0.0/1.0", "1.0/1.0")
+        m.push_to_csv(d)
+        row = pd.DataFrame(data={k: [v] for k, v in m._row_at(m.position).items()}, columns=cols)
+        ref = row if ref is None else pd.concat([ref, row], ignore_index=True)
+        if len(ref) > cap:
+            ref = ref.drop(ref.index.min())
+        assert open(os.path.join(d, "memory_pool.csv")).read() == ref.to_csv(), i
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_csv_image_follows_pandas_dtype_promotion(tmp_path, case):
+    """ADVICE r1: when pandas promotes a column (an int64 column meets a typed float: every past row is rewritten "0" -> "0.0";
+    a 0-d array cell turns the column into objects that keep their own text) the text-row image must do the same."""
+    pre = (",sequence,scribble_iter,n_interaction,n_interaction_next,action,reward_step,reward_done,done,state_iou,next_state_iou,"
+           "annotated_frames,next_annotated_frames\n" + "".join(f"{i},s,1,{i+1},{i+2},3,1,0,False,0.1/0.2,0.6/0.7,0.0/1.0,1.0/1.0\n" for i in range(3)))
+    cases = [([np.array(0), np.array(0), 0.25, np.array(0), np.array(0), np.array(0), np.array(0)], None),
+             ([0.5, np.array(0), np.array(1)], None),
+             ([0, 0, 0.25, 1, 0, 0, 2], None),
+             ([np.float64(0.5), 1, np.float64(0.25), np.array(0), 3, 0.5], None),
+             ([1, 2, np.float64(0.5), 3, 4, 5, 6, 7], None),
+             ([np.float64(0.5), 1, np.array(0)], pre)]          # int-valued column loaded from a file, then a float pushed
+    values, preload = cases[case]
+    _push_sequence_against_pandas(tmp_path, values, cap=10 if preload else 4, preload=preload)
