@@ -26,6 +26,7 @@ struct BlockPlan {
     size_t cat_fw_off;            // bf16: the concatenated weights in MFMA-operand order
     size_t cat_w_off, cat_b_off;  // first blocks: conv3 | downsample concatenated along K, bias sum (conv3 absorbs the downsample conv)
     size_t f1_off, f2_off, f3_off;  // bf16, identity blocks: conv1/2/3 weights in MFMA-operand order (0 = none)
+    size_t fwd1_off;                // bf16, res3's first block: conv1 in MFMA-operand order for res2's last block (conv1 forwarding)
 };
 
 struct Plan {
@@ -79,6 +80,8 @@ static Plan make_plan(int dtype) {
                     bp.f1_off = take((size_t)planes[s] * inpl * es);
                     bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
                 }
+                if (dtype == IVOSW_BF16 && s == 1)       // res3's first 1x1 runs inside res2's last block (conv1 forwarding)
+                    bp.fwd1_off = take((size_t)planes[s] * inpl * es);
             } else if (dtype == IVOSW_BF16) {
                 bp.f1_off = take((size_t)planes[s] * inpl * es);
                 bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
@@ -181,6 +184,8 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
             if (bp.f3_off) launch_fragpack(base + c3.w_off, c3.Cout, c3.Cin, base + bp.f3_off, st);
         }
     for (const BlockPlan& bp : P.blocks)
+        if (bp.fwd1_off) launch_fragpack(base + P.convs[bp.c1].w_off, P.convs[bp.c1].Cout, P.convs[bp.c1].Cin, base + bp.fwd1_off, st);
+    for (const BlockPlan& bp : P.blocks)
         if (bp.ds >= 0) {
             const ConvPlan &c3 = P.convs[bp.c3], &cd = P.convs[bp.ds];
             launch_concat_k(base + c3.w_off, reinterpret_cast<const float*>(base + c3.b_off), c3.Cin, base + cd.w_off,
@@ -262,7 +267,11 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
     const int cs[4] = {chunk, chunk * 2, chunk * 4, chunk * 8};
 
     // one bottleneck stage (K5) on nb frames: x -> out (the last block writes straight into `out`)
-    auto run_stage = [&](int s, const char* x_in, int nb, char* out) {
+    // conv1 forwarding through res2 (tunable FWD2): block b of res2 also applies block b+1's first 1x1 to its output tile while
+    // it is on chip; the last block applies res3's first 1x1, so that layer (a 0.8 GB pass over HBM) is never launched
+    const bool fwd2 = dtype == IVOSW_BF16 && tune_get("FWD2", 1) && tune_get("FUSE_WIDE", 1) && tune_get("FUSE_WIDE2", 1) &&
+                      tune_get("HALO64S", 1) && tune_get("HALO64S_DS", 1) && P.blocks[3].fwd1_off;
+    auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {
         const char* x = x_in;
         int hw = hw_in[s];
         for (int b = 0; b < nblk[s]; ++b) {
@@ -288,6 +297,16 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                     q.ds = 1; q.fc = base + bp.cat_fw_off; q.bc = reinterpret_cast<const float*>(base + bp.cat_b_off);
                 }
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
+                if (s == 0 && fwd2) {
+                    // t1 ping-pong: b0 -> m2 -> b1 -> ds -> b2 -> m1 (res3's t1 for the frames of the enclosing res3 chunk)
+                    const BlockPlan& nx = P.blocks[first_blk[0] + b + 1];          // the next block (res3's first after b == 2)
+                    const ConvPlan& n1c = P.convs[nx.c1];
+                    q.t1in = b == 0 ? nullptr : (b == 1 ? bf.m2 : bf.ds);
+                    q.t1out = b == 0 ? bf.m2 : (b == 1 ? bf.ds : bf.m1 + (size_t)foff * 64 * 64 * 128 * es);
+                    q.fd = base + (b == 2 ? nx.fwd1_off : nx.f1_off);
+                    q.bd = reinterpret_cast<const float*>(base + n1c.b_off);
+                    q.nd = n1c.Cout;
+                }
                 if (bp.ds < 0 && bneck_wide_fusable(q) && bneck_stage_fusable(q) && b + 1 < nblk[s]) {
                     // the rest of the stage is identity blocks of this shape: chain them inside one launch
                     BneckStageArgs sa{};
@@ -331,7 +350,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                     continue;
                 }
             }
-            mk(c1, x, hw, hw, nullptr, bf.m1, 1);
+            if (!(s == 1 && b == 0 && fwd2)) mk(c1, x, hw, hw, nullptr, bf.m1, 1);     // forwarded: res2's last block wrote it
             mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
             const void* idt = x;
             if (bp.ds >= 0 && tune_get("FUSE_DS", 1)) {
@@ -387,18 +406,18 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                     }
                     tap(3, bf.pa, (size_t)nb * 64 * 64 * 64 * es);
                     char* o2 = bf.in[0] + (size_t)(f0 - f1) * E_OUT[0] * es;
-                    run_stage(0, bf.pa, nb, o2);
+                    run_stage(0, bf.pa, nb, o2, f0 - f1);
                     tap(4, o2, nb * E_OUT[0] * es);
                 }
                 char* o3 = bf.in[1] + (size_t)(f1 - f2) * E_OUT[1] * es;
-                run_stage(1, bf.in[0], n1, o3);
+                run_stage(1, bf.in[0], n1, o3, 0);
                 tap(5, o3, n1 * E_OUT[1] * es);
             }
             char* o4 = bf.in[2] + (size_t)(f2 - f3) * E_OUT[2] * es;
-            run_stage(2, bf.in[1], n2, o4);
+            run_stage(2, bf.in[1], n2, o4, 0);
             tap(6, o4, n2 * E_OUT[2] * es);
         }
-        run_stage(3, bf.in[2], n3, bf.pa);  // c0*8 frames x 131k elements == c0 * E_BIG: fits a ping-pong buffer
+        run_stage(3, bf.in[2], n3, bf.pa, 0);  // c0*8 frames x 131k elements == c0 * E_BIG: fits a ping-pong buffer
         tap(7, bf.pa, n3 * E_OUT[3] * es);
         // K6: 8x8 average pool + fc1
         span_close(st);

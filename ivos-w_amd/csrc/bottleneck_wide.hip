@@ -782,7 +782,38 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
     for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.ba + ctw * 32 + 8 * g + 4 * lhalf);
 
     // ================================================================ phase A
-    {
+    if constexpr (TIN) {
+        // t1 arrives from the previous block (its phase D): 180 halo rows x 128 B, rows outside the frame are the 3x3's zero
+        // padding.  1440 16-byte chunks over 512 threads, through registers into the padded-row image.
+        const bf16_t* T1 = static_cast<const bf16_t*>(p.t1in) + (size_t)b * HW * HW * C;
+        uint4 tv[3];
+        unsigned ta[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + 512 * i;
+            const int hr = id >> 3, ch = id & 7;
+            const int hy = hr / HTX, hx = hr - hy * HTX;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = hr < HR && y >= 0 && y < HW && x >= 0 && x < HW;
+            tv[i] = ok ? *reinterpret_cast<const uint4*>(T1 + ((size_t)y * HW + x) * C + ch * 8) : make_uint4(0, 0, 0, 0);
+            ta[i] = hr < HR ? lds_base + T1_OFF + hr * T1R + ch * 16 : 0xffffffffu;
+        }
+        if (tid < 128) *reinterpret_cast<float*>(lds + BAB_OFF + tid * 4) = bias_v;
+        else if (tid < 384) *reinterpret_cast<float*>(lds + BC_OFF + (tid - 128) * 4) = bias_v;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) wnb[j] = *wfrag(p.fb, ctw, 36, (wave >> 2) * 18 + j, lane);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (ta[i] != 0xffffffffu) {
+                u32x4 v = {tv[i].x, tv[i].y, tv[i].z, tv[i].w};
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ta[i]), "v"(v) : "memory");
+            }
+        stamp(1);
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(2);
+    } else {
         const int grp = wave >> 1;
         const bool two = grp < 2;                    // pixel tiles grp and grp + 4 (< 6)
         f32x16 acc[2];
@@ -1058,6 +1089,74 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
             }
         }
         stamp(5);
+        // phase D (ND > 0): the next block's conv1 on this tile's y, half a tile (64 pixels) at a time.  The y half sits in LDS
+        // as four 64-channel slices of the swizzled [64 rows][128 B] image at [0, 32768): t1 / t2 / x are dead by now.
+        constexpr int YS = 64 * ROWB;                // one slice of the half image
+        bf16_t* T1O = ND > 0 ? static_cast<bf16_t*>(p.t1out) + (size_t)b * HW * HW * ND : nullptr;
+        auto phase_d = [&](int half) {
+            lds_wait();
+            __builtin_amdgcn_s_barrier();            // every wave's part of the y half is in LDS
+            asm volatile("" ::: "memory");
+            constexpr int NT = (ND / 32) * 2;        // output tiles of the half: channel tiles x 2 pixel tiles
+            if (wave < NT) {
+                const int ct = wave % (ND / 32), pt = wave / (ND / 32);
+                f32x16 ad;
+                {
+                    float4 bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bd + ct * 32 + 8 * g + 4 * lhalf);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { ad[4 * g] = bq[g].x; ad[4 * g + 1] = bq[g].y; ad[4 * g + 2] = bq[g].z; ad[4 * g + 3] = bq[g].w; }
+                }
+                const int row = pt * 32 + lrow;
+                // addresses as (one register + immediates): left to itself hipcc computes all 16 weight pointers and 16 LDS
+                // addresses ahead of the store pass and spills them (25 dwords of scratch traffic per tile)
+                unsigned ya[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ya[ks] = lds_base + row * ROWB + (((2 * ks + lhalf) ^ ((row >> 1) & 7)) << 4);
+                const uint4* wb = wfrag(p.fd, ct, 16, 0, lane);
+                asm volatile("" : "+v"(wb), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]));
+                uint4 wv[2][4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wv[0][ks] = wb[ks * 64];
+                auto slice = [&](auto slc) {
+                    constexpr int SL = decltype(slc)::value;
+                    if constexpr (SL < 3) {
+                        const uint4* wn_ = wb + (SL + 1) * 256;
+                        asm volatile("" : "+v"(wn_));
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) wv[(SL + 1) & 1][ks] = wn_[ks * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    u32x4 pd[4];
+                    pd[0] = lds_read_b128_o<SL * YS>(ya[0]); pd[1] = lds_read_b128_o<SL * YS>(ya[1]);
+                    pd[2] = lds_read_b128_o<SL * YS>(ya[2]); pd[3] = lds_read_b128_o<SL * YS>(ya[3]);
+                    lds_wait();
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) ad = mfma_bf16(as_u32x4(wv[SL & 1][ks]), pd[ks], ad);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                slice(std::integral_constant<int, 0>{}); slice(std::integral_constant<int, 1>{});
+                slice(std::integral_constant<int, 2>{}); slice(std::integral_constant<int, 3>{});
+                const int q = half * 64 + row;
+                bf16_t* o = T1O + ((size_t)(y0 + (q >> 4)) * HW + x0 + (q & 15)) * ND + ct * 32 + 4 * lhalf;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 pk;
+                    pk.x = pack2_bf16(fmaxf(ad[4 * g], 0.f), fmaxf(ad[4 * g + 1], 0.f));
+                    pk.y = pack2_bf16(fmaxf(ad[4 * g + 2], 0.f), fmaxf(ad[4 * g + 3], 0.f));
+                    *reinterpret_cast<uint2*>(o + 8 * g) = pk;
+                }
+            }
+            if (half == 0) {
+                __builtin_amdgcn_s_barrier();        // the image is free for the second half
+                asm volatile("" ::: "memory");
+            }
+        };
+        if constexpr (ND > 0) {
+            __builtin_amdgcn_s_barrier();            // every wave is past its last read of t2 (DS: and of x)
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1066,7 +1165,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
                 *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
             }
             uint4 rn[2];
-            if (i < 3) {
+            const bool carry = !(ND > 0 && i == 1);  // phase D sits behind item 1: the next residual is requested after it (registers)
+            if (i < 3 && carry) {
 #pragma unroll
                 for (int it = 0; it < 2; ++it) rn[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(xrow + (2 * (i + 1) + it) * RPITCH);
             }
@@ -1082,6 +1182,20 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
                 for (int k = 0; k < 4; ++k)
                     pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
                 *reinterpret_cast<uint4*>(yrow + (2 * i + it) * RPITCH) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if constexpr (ND > 0) {              // the same 8 channels of this pixel into the y half image
+                    const int row = (i & 1) * 32 + pr, c16 = wave * 4 + u;
+                    const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
+                    const unsigned a = lds_base + (c16 >> 3) * YS + row * ROWB + (((c16 & 7) ^ ((row >> 1) & 7)) << 4);
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(v) : "memory");
+                }
+            }
+            if constexpr (ND > 0) {
+                if (i == 1) phase_d(0);
+                if (i == 3) phase_d(1);
+            }
+            if (i < 3 && !carry) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) rn[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(xrow + (2 * (i + 1) + it) * RPITCH);
             }
             if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
         }
@@ -1305,8 +1419,11 @@ void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.ds ? nullptr : a.x;
     void* tok = prof_begin(d, 2, st);
     if (a.Cmid == 128) hipLaunchKernelGGL((bneck_halo_kernel<128>), dim3(a.B * 4), dim3(512), 0, st, a);
-    else if (a.ds) hipLaunchKernelGGL(bneck_halo64s_kernel<true>, dim3(a.B * 32), dim3(512), 0, st, a);
-    else if (a.Cmid == 64 && tune_get("HALO64S", 1)) hipLaunchKernelGGL(bneck_halo64s_kernel<false>, dim3(a.B * 32), dim3(512), 0, st, a);
+    else if (a.ds && a.t1out && a.nd == 64) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 64>), dim3(a.B * 32), dim3(512), 0, st, a);
+    else if (a.ds) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 0>), dim3(a.B * 32), dim3(512), 0, st, a);
+    else if (a.Cmid == 64 && a.t1in && a.t1out && a.nd == 64) hipLaunchKernelGGL((bneck_halo64s_kernel<false, true, 64>), dim3(a.B * 32), dim3(512), 0, st, a);
+    else if (a.Cmid == 64 && a.t1in && a.t1out && a.nd == 128) hipLaunchKernelGGL((bneck_halo64s_kernel<false, true, 128>), dim3(a.B * 32), dim3(512), 0, st, a);
+    else if (a.Cmid == 64 && tune_get("HALO64S", 1)) hipLaunchKernelGGL((bneck_halo64s_kernel<false, false, 0>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64) hipLaunchKernelGGL((bneck_halo_kernel<64>), dim3(a.B * 16), dim3(512), 0, st, a);
     else if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
     else if (tune_get("FUSE_WIDE5", 0) == 2) hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 1>), dim3(a.B), dim3(512), 0, st, a);   // one frame per workgroup

@@ -374,3 +374,24 @@ def test_bf16_decisions_agree_with_fp32(dev):
     if top2[1] - top2[0] > 4 * np.abs(Q[0] - Q[1]).max():
         assert a16 == a32
     assert Q[1][a32] - Q[1][a16] <= 2 * np.abs(Q[0] - Q[1]).max()
+
+
+def test_conv1_forwarding_through_res2_is_bit_identical(dev, net16):
+    """bf16 mode: every res2 block also applies the NEXT block's first 1x1 to its output tile while it is on chip (tunable
+    FWD2=1, default), so the next block starts from t1 instead of re-reading the 256-channel halo and res3's first 1x1 layer is
+    never launched.  Same bf16 inputs, same K order of the same MFMAs -> the stage outputs and the scores must not move by a
+    bit against FWD2=0, for a full, an odd and a chunked batch (two res2 chunks feeding one res3 chunk)."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge, chunk in ((8, True, 0), (3, False, 0), (6, False, 2)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
+        got = {}
+        try:
+            for mode in (1, 0):
+                lib.ivosw_tune_set(b"FWD2", mode)
+                got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3")] + [net(ttf, ttp).clone()]
+        finally:
+            lib.ivosw_tune_set(b"FWD2", 1)
+        for a, b, nm in zip(got[1], got[0], ("res2", "res3", "scores")):
+            assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
