@@ -1100,14 +1100,9 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
             constexpr int NT = (ND / 32) * 2;        // output tiles of the half: channel tiles x 2 pixel tiles
             if (wave < NT) {
                 const int ct = wave % (ND / 32), pt = wave / (ND / 32);
-                f32x16 ad;
-                {
-                    float4 bq[4];
+                f32x16 ad;                           // from zero, bias added after the sum: the order of the kernels this replaces
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(p.bd + ct * 32 + 8 * g + 4 * lhalf);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) { ad[4 * g] = bq[g].x; ad[4 * g + 1] = bq[g].y; ad[4 * g + 2] = bq[g].z; ad[4 * g + 3] = bq[g].w; }
-                }
+                for (int r = 0; r < 16; ++r) ad[r] = 0.f;
                 const int row = pt * 32 + lrow;
                 // addresses as (one register + immediates): left to itself hipcc computes all 16 weight pointers and 16 LDS
                 // addresses ahead of the store pass and spills them (25 dwords of scratch traffic per tile)
@@ -1142,9 +1137,10 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
                 bf16_t* o = T1O + ((size_t)(y0 + (q >> 4)) * HW + x0 + (q & 15)) * ND + ct * 32 + 4 * lhalf;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    const float4 bq = *reinterpret_cast<const float4*>(p.bd + ct * 32 + 8 * g + 4 * lhalf);
                     uint2 pk;
-                    pk.x = pack2_bf16(fmaxf(ad[4 * g], 0.f), fmaxf(ad[4 * g + 1], 0.f));
-                    pk.y = pack2_bf16(fmaxf(ad[4 * g + 2], 0.f), fmaxf(ad[4 * g + 3], 0.f));
+                    pk.x = pack2_bf16(fmaxf(ad[4 * g] + bq.x, 0.f), fmaxf(ad[4 * g + 1] + bq.y, 0.f));
+                    pk.y = pack2_bf16(fmaxf(ad[4 * g + 2] + bq.z, 0.f), fmaxf(ad[4 * g + 3] + bq.w, 0.f));
                     *reinterpret_cast<uint2*>(o + 8 * g) = pk;
                 }
             }
