@@ -65,14 +65,39 @@ def dist_setup(n):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if n > 1 and world != n:
         raise SystemExit(f"--gpus {n} needs torch.distributed.run with nproc-per-node {n} (WORLD_SIZE={world})")
+    # --backend gloo + IVOSW_BENCH_SAME_DEVICE=1: every rank on cuda:0 with host-staged collectives — the only way to run the
+    # multi-rank code path on a one-GPU box (tests/test_gpu_dist.py); the driver's 2/4/8-GPU runs use nccl = RCCL over xGMI
+    if os.environ.get("IVOSW_BENCH_SAME_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_
-        dist_.init_process_group("nccl", device_id=dev)
+        if BACKEND[0] == "nccl":
+            dist_.init_process_group("nccl", device_id=dev)
+        else:
+            dist_.init_process_group(BACKEND[0])
         dist = dist_
     return rank, world, dev, dist
+
+
+BACKEND = ["nccl"]
+
+
+def reduce_scalar(dist, value, op, dev):
+    """max / min of a host scalar over the ranks (a CPU tensor under gloo, a device tensor under RCCL)."""
+    t = torch.tensor([value], dtype=torch.float64, device=dev if BACKEND[0] == "nccl" else "cpu")
+    dist.all_reduce(t, op=op)
+    return float(t.item())
+
+
+def allreduce_grads(dist, flat_grad):
+    if BACKEND[0] == "nccl":
+        dist.all_reduce(flat_grad)                      # RCCL over xGMI
+    else:
+        from ivos_w_amd import parallel
+        parallel.allreduce_grads(flat_grad)             # gloo: staged through host memory
 
 
 def timed(fn, steps, warmup, dev, dist, min_warm_s=0.0, before=None, after=None):
@@ -85,9 +110,7 @@ def timed(fn, steps, warmup, dev, dist, min_warm_s=0.0, before=None, after=None)
     def warm_enough():
         el = time.perf_counter() - t_w
         if dist is not None:                   # every rank must take the same decision (the step may contain a collective)
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            el = float(t.item())
+            el = reduce_scalar(dist, el, dist.ReduceOp.MIN, dev)
         return el >= min_warm_s
     while min_warm_s > 0 and not warm_enough():
         for _ in range(max(1, warmup)):
@@ -108,9 +131,7 @@ def timed(fn, steps, warmup, dev, dist, min_warm_s=0.0, before=None, after=None)
     if after is not None:
         after()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = reduce_scalar(dist, dt, dist.ReduceOp.MAX, dev)
     return dt
 
 
@@ -275,7 +296,7 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
             torch.randint(0, nrep, (B,), device=dev, generator=gen, out=cap.idx)
             cap.launch()
         if world > 1:
-            dist.all_reduce(agent.policy_net.flat_grad)
+            allreduce_grads(dist, agent.policy_net.flat_grad)
             agent.optimizer.grad_scale = 1.0 / world
         if cap is None or not fused:
             agent.optimizer.step()
@@ -419,6 +440,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--min-warm-s", type=float, default=1.0, help="extend the warm-up to at least this many seconds (steady-state clocks)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode sub-record")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--dqn-eager", action="store_true", help="DQN leg with eager launches instead of the captured HIP graph")
     ap.add_argument("--workload", choices=["assess", "dqn"], default="assess")
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (assessment)")
@@ -432,6 +454,7 @@ def main():
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    BACKEND[0] = args.backend
     rank, world, dev, dist = dist_setup(args.gpus)
     lib = L.lib()
     # ablation guard: the measured library must be the default build, with no debug switch in the environment
@@ -451,7 +474,7 @@ def main():
                      "dqn": dict({"metric": "dqn_agent_steps_per_sec", "value": round(dqn_sps, 1), "unit": "minibatch-steps/s (all ranks)",
                                   "transitions_per_sec": round(dqn_sps * args.minibatch, 1), "minibatch_per_gpu": args.minibatch,
                                   "replay": args.replay, "T": 25, "steps": args.dqn_steps,
-                                  "dtype": "f32", "collective": "rccl all_reduce(724KB)" if world > 1 else None}, **dqn_info)})
+                                  "dtype": "f32", "collective": (f"{'rccl' if args.backend == 'nccl' else 'gloo (host-staged)'} all_reduce(724KB)") if world > 1 else None}, **dqn_info)})
         line.update(extra)
     else:
         sps, dt, info = bench_dqn(args, rank, world, dev, dist, args.steps, args.warmup)

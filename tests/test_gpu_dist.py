@@ -102,3 +102,30 @@ def test_world2_product_path_matches_single_process_full_batch():
     assert close.mean() > 0.999, close.mean()
     # the target-sync decisions (shared coin) are those of the single process
     assert np.array_equal(res[0][-1][2], res[0][-1][1]) == bool(torch.equal(agent.target_net.flat, agent.policy_net.flat))
+
+
+def test_bench_multi_rank_branch_under_torchrun(tmp_path):
+    """bench.py's N > 1 branch exactly as the driver launches it (torch.distributed.run, one process per rank, barrier + max over
+    ranks, rank 0 prints the line) — on this one-GPU box with both ranks on cuda:0 and the gloo backend staging the collective
+    through host memory (two ranks cannot share a device under RCCL).  Frames are sharded (weak scaling), the DQN leg all-reduces
+    its gradient arena every step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ, IVOSW_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--min-warm-s", "0",
+           "--batch", "16", "--dqn-steps", "30", "--backend", "gloo", "--no-fp32"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0 and d["checked"] is True
+    assert d["config"]["parallelism"] == "frames sharded x2" and "cpu_baseline" not in d
+    assert d["dqn"]["value"] > 0 and "all_reduce" in d["dqn"]["collective"] and d["dqn"]["graph"] is True
