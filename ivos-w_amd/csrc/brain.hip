@@ -708,6 +708,7 @@ struct DqnWs {
 int tune_get(const char* key, int dflt);   // capi.cpp
 
 static constexpr int WG_SPLIT = 16;
+static constexpr int WG_SPLIT_MAX = 32;   // slab sets of the two long-K weight gradients are sized for this (tunables DQN_SPLIT_HH / _IH)
 
 // One helper stream + four events per device: the only state the library keeps between calls (documented in
 // INTEGRATION.md).  Creation is serialised and all-or-nothing; ivosw_dqn_loss_grad holds the device's mutex while it
@@ -747,7 +748,7 @@ static size_t dqn_ws_floats(int B, int T) {
     n += 2 * r * 2;                        // xcat
     n += B + (size_t)B * 128 * 2 + (size_t)B * 256 * 2;  // dq, dd1c, w4term, hcc, dhc
     n += 2 * r * 512 + r * 512 + r * 128 + r * 128;       // dG, dgx, de, da1
-    n += 3 * (size_t)WG_SPLIT * 512 * 128; // split-K slabs: one set per concurrently reduced weight gradient
+    n += (size_t)(WG_SPLIT + 2 * WG_SPLIT_MAX) * 512 * 128; // split-K slabs: one set per concurrently reduced weight gradient
     return n + 8 * 512 + 64 * 32;
 }
 
@@ -832,8 +833,8 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     w.de = ar.take<float>((size_t)rows * 128);
     w.da1 = ar.take<float>((size_t)rows * 128);
     w.slabs = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
-    float* slabs2 = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
-    float* slabs3 = ar.take<float>((size_t)WG_SPLIT * 512 * 128);
+    float* slabs2 = ar.take<float>((size_t)WG_SPLIT_MAX * 512 * 128);
+    float* slabs3 = ar.take<float>((size_t)WG_SPLIT_MAX * 512 * 128);
     float* slabs4 = ar.take<float>(8 * 512);                  // row-split column sums
 
     // The step is a chain of ~40 launches that each occupy a fraction of the chip for 5-30 us: independent branches run
@@ -913,11 +914,12 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     // dWhh[512,128] = sum_{d,n,t} dG^T * hprev          (K = 2*B*T), split-K slabs
     gw[1] = GemmF32{};
     gw[1].A = w.dG; gw[1].sam = 1; gw[1].sak = 512; gw[1].B = w.pol.hprev; gw[1].sbk = 128; gw[1].sbn = 1; gw[1].ldc = 128;
-    gw[1].M = 512; gw[1].N = 128; gw[1].K = 2 * rows; gw[1].C = slabs2; gw[1].splitk = WG_SPLIT;
+    const int split_hh = std::min(WG_SPLIT_MAX, std::max(1, tune_get("DQN_SPLIT_HH", WG_SPLIT))), split_ih = std::min(WG_SPLIT_MAX, std::max(1, tune_get("DQN_SPLIT_IH", WG_SPLIT)));
+    gw[1].M = 512; gw[1].N = 128; gw[1].K = 2 * rows; gw[1].C = slabs2; gw[1].splitk = split_hh;
     // dWih[512,128] = dgx^T * e
     gw[2] = GemmF32{};
     gw[2].A = dgx_a; gw[2].A2 = dgx_a2; gw[2].sam = 1; gw[2].sak = 512; gw[2].B = e_s; gw[2].sbk = 128; gw[2].sbn = 1; gw[2].ldc = 128;
-    gw[2].M = 512; gw[2].N = 128; gw[2].K = rows; gw[2].C = slabs3; gw[2].splitk = WG_SPLIT;
+    gw[2].M = 512; gw[2].N = 128; gw[2].K = rows; gw[2].C = slabs3; gw[2].splitk = split_ih;
     // de[rows,128] = dgx * Wih
     GemmF32 gde = GemmF32{};
     gde.A = dgx_a; gde.A2 = dgx_a2; gde.sam = 512; gde.sak = 1; gde.B = policy + O_WIH; gde.sbk = 128; gde.sbn = 1; gde.C = w.de; gde.ldc = 128;
@@ -955,8 +957,8 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         c1.j[1] = ColsumJob{w.da1, state, cs_b1, cs_w1, rows, 128, 128};
         hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 2, CS), dim3(1024), 0, st, c1);
         ReduceGroup rg{};
-        rg.slabs[0] = slabs2; rg.out[0] = grads + O_WHH; rg.n[0] = 512 * 128; rg.nslab[0] = WG_SPLIT;
-        rg.slabs[1] = slabs3; rg.out[1] = grads + O_WIH; rg.n[1] = 512 * 128; rg.nslab[1] = WG_SPLIT;
+        rg.slabs[0] = slabs2; rg.out[0] = grads + O_WHH; rg.n[0] = 512 * 128; rg.nslab[0] = split_hh;
+        rg.slabs[1] = slabs3; rg.out[1] = grads + O_WIH; rg.n[1] = 512 * 128; rg.nslab[1] = split_ih;
         rg.slabs[2] = w.slabs; rg.out[2] = grads + O_W2; rg.n[2] = 128 * 128; rg.nslab[2] = WG_SPLIT;
         rg.slabs[3] = cs_b2; rg.out[3] = grads + O_B2; rg.n[3] = 128; rg.nslab[3] = CS;
         rg.slabs[4] = cs_b1; rg.out[4] = grads + O_B1; rg.n[4] = 128; rg.nslab[4] = CS;
@@ -967,8 +969,8 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.w4term, B, 128, 128, grads + O_W4);
         hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.dd1c, B, 128, 128, grads + O_B3);
         launch_gemm_f32(gw[0], s2);
-        launch_gemm_f32_splitk(gw[1], grads + O_WHH, slabs2, WG_SPLIT, s2);
-        launch_gemm_f32_splitk(gw[2], grads + O_WIH, slabs2, WG_SPLIT, s2);
+        launch_gemm_f32_splitk(gw[1], grads + O_WHH, slabs2, split_hh, s2);
+        launch_gemm_f32_splitk(gw[2], grads + O_WIH, slabs2, split_ih, s2);
         launch_gemm_f32(gde, st);
         launch_gemm_f32_splitk(gb, grads + O_W2, w.slabs, WG_SPLIT, st);
         hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, st, w.de, rows, 128, 128, grads + O_B2);

@@ -250,3 +250,33 @@ def test_entry_points_run_on_the_buffers_device_not_the_current_one(dev):
     host = (ctypes.c_float * 8)()
     assert L.lib().ivosw_brain_argmax(ctypes.cast(host, ctypes.c_void_p), 1, 8, ctypes.cast(host, ctypes.c_void_p), None) == -1
     assert b"not a device pointer" in L.lib().ivosw_last_error()
+
+
+@pytest.mark.parametrize("tun", [dict(LSTM_QUAD=0), dict(DQN_GROUP=0), dict(LSTM_QUAD=0, DQN_GROUP=0, DQN_STREAMS=0)])
+def test_alternative_kernel_paths_agree_with_the_default(dev, tun):
+    """The round-1 recurrences (LSTM_QUAD=0: gate column per thread, two barriers per step) and the ungrouped two-stream backward
+    tail (DQN_GROUP=0) stay in the library as tunables: same step, different summation orders — loss and every gradient tensor
+    within fp32 rounding of the default path (quad-layout recurrences, grouped single-stream tail)."""
+    from ivos_w_amd import _lib as L
+    from ivos_w_amd.models.agent import Agent
+    lib = L.lib()
+    tr = synth.replay_transitions(n=600, T=25, seed=3)
+    agent = Agent(dev, cfg())
+    load_brain(agent.policy_net, 0)
+    load_brain(agent.target_net, 1)
+    batch = synth.collate_np(tr, synth.minibatch_indices(0, n=600, B=128, seed=5))
+    loss0 = agent.loss_and_grads(batch).item()
+    g0 = agent.policy_net.flat_grad.cpu().numpy().copy()
+    try:
+        for k, v in tun.items():
+            lib.ivosw_tune_set(k.encode(), v)
+        loss1 = agent.loss_and_grads(batch).item()
+        g1 = agent.policy_net.flat_grad.cpu().numpy().copy()
+    finally:
+        for k in tun:
+            lib.ivosw_tune_set(k.encode(), 1)
+    np.testing.assert_allclose(loss1, loss0, rtol=1e-5)
+    for k, (off, shp) in synth.brain_offsets().items():
+        n = int(np.prod(shp))
+        s = np.abs(g0[off:off + n]).max() + 1e-30
+        assert np.abs(g1[off:off + n] - g0[off:off + n]).max() <= 2e-4 * s, (k, tun)
