@@ -344,8 +344,33 @@ def make_glue():
         json.dump(out, f, indent=1)
     print("glue_fixtures.json", out["select"], out["reward"]["done"])
 
+# ----------------------------------------------------------------------------- Agent.action, train phase
+def make_action():
+    """40 consecutive Agent.action calls of the reference in the TRAIN phase (epsilon-greedy, models/agent.py:168-196): seeded
+    python / numpy RNGs, the seeded Brain weights, a fresh state per call.  Records every returned index, which branch took it
+    and the threshold — the greedy picks pin the bit-exact argmax, the random ones the RNG call sequence."""
+    import io
+    import random
+    import contextlib
+    from models.agent import Agent
+    agent = Agent(torch.device("cpu"), agent_cfg(phase="train"))
+    agent.policy_net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.brain_state_dict(0).items()})
+    random.seed(1234)
+    np.random.seed(1234)
+    out = dict(T=25, seed=1234, calls=[])
+    for i in range(40):
+        state = brain_inputs(1, 25, 500 + i)[0].astype(np.float64)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            a = agent.action(state)
+        out["calls"].append(dict(action=int(a), random="randomly" in buf.getvalue(), steps_done=int(agent.steps_done)))
+    with open(os.path.join(HERE, "agent_action.json"), "w") as f:
+        json.dump(out, f)
+    print("agent_action.json", sum(c["random"] for c in out["calls"]), "random of", len(out["calls"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["brain", "dqn", "assess", "replay", "glue"]
+    which = sys.argv[1:] or ["brain", "dqn", "assess", "replay", "glue", "action"]
     os.chdir("/tmp")
     install_shims()
     torch.set_num_threads(8)

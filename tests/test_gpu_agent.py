@@ -280,3 +280,27 @@ def test_alternative_kernel_paths_agree_with_the_default(dev, tun):
         n = int(np.prod(shp))
         s = np.abs(g0[off:off + n]).max() + 1e-30
         assert np.abs(g1[off:off + n] - g0[off:off + n]).max() <= 2e-4 * s, (k, tun)
+
+
+def test_train_phase_epsilon_greedy_vs_reference_golden(dev, golden_dir):
+    """Agent.action in the TRAIN phase (models/agent.py:168-196): 40 consecutive calls of the imported reference with seeded RNGs
+    (tests/golden/make_goldens.py action) against the product class — the same branch every call (same epsilon schedule, same
+    RNG call sequence), the same random index, and on the 8 greedy calls the bit-exact argmax of the HIP Q-values."""
+    import io
+    import json
+    import random
+    import contextlib
+    from ivos_w_amd.models.agent import Agent
+    gold = json.load(open(os.path.join(golden_dir, "agent_action.json")))
+    agent = Agent(dev, cfg(update_rate=0.05, phase="train"))
+    load_brain(agent.policy_net, 0)
+    random.seed(gold["seed"])
+    np.random.seed(gold["seed"])
+    for i, want in enumerate(gold["calls"]):
+        state = synth.brain_inputs(1, gold["T"], 500 + i)[0].astype(np.float64)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            a = agent.action(state)
+        assert ("randomly" in buf.getvalue()) == want["random"], i
+        assert int(a) == want["action"] and agent.steps_done == want["steps_done"], (i, int(a), want)
+    assert sum(not c["random"] for c in gold["calls"]) >= 5          # the fixture does exercise the greedy branch
