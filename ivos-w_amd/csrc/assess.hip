@@ -271,6 +271,9 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
     // it is on chip; the last block applies res3's first 1x1, so that layer (a 0.8 GB pass over HBM) is never launched
     const bool fwd2 = dtype == IVOSW_BF16 && tune_get("FWD2", 1) && tune_get("FUSE_WIDE", 1) && tune_get("FUSE_WIDE2", 1) &&
                       tune_get("HALO64S", 1) && tune_get("HALO64S_DS", 1) && P.blocks[3].fwd1_off;
+    // ... and res2's last block then writes its output at the even pixels only (compact [nb,32,32,256]): with conv1 forwarded, the
+    // only reader left is res3's stride-2 downsample.  Off when an intermediate is tapped (the res2 tap wants the whole tensor).
+    const bool ys2 = fwd2 && tap_stage == 0 && tune_get("FUSE_DS", 1) && tune_get("YS2", 1);
     auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {
         const char* x = x_in;
         int hw = hw_in[s];
@@ -306,6 +309,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                     q.fd = base + (b == 2 ? nx.fwd1_off : nx.f1_off);
                     q.bd = reinterpret_cast<const float*>(base + n1c.b_off);
                     q.nd = n1c.Cout;
+                    q.y_s2 = (b == 2 && ys2) ? 1 : 0;
                 }
                 if (bp.ds < 0 && bneck_wide_fusable(q) && bneck_stage_fusable(q) && b + 1 < nblk[s]) {
                     // the rest of the stage is identity blocks of this shape: chain them inside one launch
@@ -363,6 +367,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                 q.res = nullptr; q.y = y; q.B = nb; q.H = ho; q.W = ho; q.Cin = c3.Cin; q.Ho = ho; q.Wo = ho; q.Cout = c3.Cout;
                 q.KH = 1; q.KW = 1; q.stride = 1; q.pad = 0; q.relu = 1;
                 q.x2 = x; q.Cin2 = cd.Cin; q.H2 = hw; q.W2 = hw; q.stride2 = cd.stride;
+                if (s == 1 && ys2) { q.H2 = hw / 2; q.W2 = hw / 2; q.stride2 = 1; }      // res2's output arrives already subsampled
                 if (dtype == IVOSW_BF16 && bp.cat_fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + bp.cat_fw_off, st);
                 else launch_conv(q, dtype, false, st);
                 x = y;
@@ -405,7 +410,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                         launch_maxpool(bf.stem, nb, 128, 128, 64, dtype, bf.pa, st);
                     }
                     tap(3, bf.pa, (size_t)nb * 64 * 64 * 64 * es);
-                    char* o2 = bf.in[0] + (size_t)(f0 - f1) * E_OUT[0] * es;
+                    char* o2 = bf.in[0] + (size_t)(f0 - f1) * (ys2 ? E_OUT[0] / 4 : E_OUT[0]) * es;
                     run_stage(0, bf.pa, nb, o2, f0 - f1);
                     tap(4, o2, nb * E_OUT[0] * es);
                 }

@@ -741,9 +741,11 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
 // parks the finished y tile in LDS (two halves of 64 pixels x 256 channels, 32 KB, over the dead t1 / t2 / x images) and phase D
 // applies the NEXT block's conv1 (256 -> ND, K = 256) to it: t1out = relu(Wd y + bd).  Per tile: 23 + 64 (residual) KB in,
 // 64 + 16 KB out instead of 92 + 64 in, 64 out; no halo recompute; and res3's first 1x1 layer (a 0.8 GB HBM pass) disappears.
-template <bool DS, bool TIN, int ND>
+// YS2: the consumer of y is a stride-2 1x1 convolution only (res3's downsample; its conv1 was forwarded), so only the even
+// pixels are written, compactly, as [B,32,32,256]: 16 instead of 64 KB per tile.
+template <bool DS, bool TIN, int ND, bool YS2 = false>
 __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) {
-    static_assert(!(DS && TIN) && (ND == 0 || ND == 64 || ND == 128), "variants");
+    static_assert(!(DS && TIN) && (ND == 0 || ND == 64 || ND == 128) && (!YS2 || ND > 0), "variants");
     constexpr int C = 64, CIN = DS ? 64 : 256, COUT = 256, NKA = CIN / 64, HW = 64, BTY = 8, BTX = 16, HTX = 18, HR = 180, NGA = 23;
     constexpr int SLOT = 24576, T1_OFF = DS ? SLOT : 0, T2_OFF = SLOT, STG_OFF = DS ? 2 * SLOT : 40960;
     // biases wait in LDS (a global load at the head of every epilogue would expose an L2 round trip each time): behind the
@@ -1023,6 +1025,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
         constexpr size_t RPITCH = (size_t)HW * COUT;
         const bf16_t* xrow = X + pix(prr) + cofs;
         bf16_t* yrow = Y + pix(prr) + cofs;
+        if constexpr (YS2)                           // compact even-pixel output: row (y0 + 2i) / 2, column (x0 + prr) / 2
+            yrow = static_cast<bf16_t*>(p.y) + (size_t)b * (HW / 2) * (HW / 2) * COUT + ((size_t)(y0 / 2) * (HW / 2) + (x0 + prr) / 2) * COUT + cofs;
         uint4 rr[2];
 #pragma unroll
         for (int it = 0; it < 2; ++it) rr[it] = DS ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(xrow + it * RPITCH);
@@ -1177,7 +1181,11 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
-                *reinterpret_cast<uint4*>(yrow + (2 * i + it) * RPITCH) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if constexpr (YS2) {
+                    if (it == 0 && !(prr & 1)) *reinterpret_cast<uint4*>(yrow + (size_t)i * (HW / 2) * COUT) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                } else {
+                    *reinterpret_cast<uint4*>(yrow + (2 * i + it) * RPITCH) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
                 if constexpr (ND > 0) {              // the same 8 channels of this pixel into the y half image
                     const int row = (i & 1) * 32 + pr, c16 = wave * 4 + u;
                     const u32x4 v = {pk[0], pk[1], pk[2], pk[3]};
@@ -1418,6 +1426,7 @@ void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     else if (a.ds && a.t1out && a.nd == 64) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 64>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.ds) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 0>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64 && a.t1in && a.t1out && a.nd == 64) hipLaunchKernelGGL((bneck_halo64s_kernel<false, true, 64>), dim3(a.B * 32), dim3(512), 0, st, a);
+    else if (a.Cmid == 64 && a.t1in && a.t1out && a.nd == 128 && a.y_s2) hipLaunchKernelGGL((bneck_halo64s_kernel<false, true, 128, true>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64 && a.t1in && a.t1out && a.nd == 128) hipLaunchKernelGGL((bneck_halo64s_kernel<false, true, 128>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64 && tune_get("HALO64S", 1)) hipLaunchKernelGGL((bneck_halo64s_kernel<false, false, 0>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64) hipLaunchKernelGGL((bneck_halo_kernel<64>), dim3(a.B * 16), dim3(512), 0, st, a);

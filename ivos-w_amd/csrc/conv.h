@@ -64,6 +64,7 @@ struct BneckWideArgs {
     void* t1out;                       // NHWC [B,H,W,nd]: the NEXT block's conv1 applied to this block's output y, or NULL
     const void* fd; const float* bd;   // that conv1 [nd][4*Cmid] in fragment order, and its bias
     int nd;                            // 64 (next block of res2) or 128 (first block of res3)
+    int y_s2;                          // 1: y is written at the even pixels only, compactly [B,H/2,W/2,4*Cmid] (its only consumer is a stride-2 1x1)
 };
 // a run of consecutive identity blocks of one stage (res4: one frame per workgroup) in ONE launch
 struct BneckStageArgs {
