@@ -387,6 +387,12 @@ __global__ __launch_bounds__(512) void bneck_wide_kernel(BneckWideArgs p) {
 template <int C, int HW, int FR>
 __global__ __launch_bounds__(512) void bneck_wide_stage_kernel(BneckStageArgs s) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[WIDE_LDS];   // the ONLY LDS object
+    if (s.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        // block b runs on XCD b % 8: (b >> 3) & 1 splits the workgroups of EVERY XCD into two halves, so that the memory phases
+        // of one half meet the MFMA-only phase B of the other on the same XCD-to-memory link
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)s.stagger) __builtin_amdgcn_s_sleep(32);
+    }
     for (int j = 0; j < s.n; ++j) {
         if (j > 0) {
             // workgroup scope: producer and consumer waves share this CU's write-through L1 (an agent-scope release writes the
@@ -1445,6 +1451,11 @@ void launch_bneck_wide_stage(const BneckStageArgs& s_in, hipStream_t st) {
     d.B = a.B * s.n;                   // report row: n blocks x B frames of the same shape
     d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.x;
     void* tok = prof_begin(d, 2, st);
+    // Every second workgroup of each XCD starts ~half a block period late (110 k cycles), so that the memory phases (A: x in, C:
+    // residual in / y out, 54 % of a block's time, bound by the XCD's path to memory) of one half meet the MFMA-only phase B of the
+    // other: 693 -> 667 and 704 -> 682 us for the five chained blocks at B = 256 INCLUDING the 77 us of start skew (round 1 delayed
+    // the odd workgroups = whole XCDs, which cannot help a per-XCD limit, and saw nothing).  Only when every CU has a workgroup.
+    s.stagger = tune_get("STAGGER", a.B >= 200 ? 110000 : 0);
     hipLaunchKernelGGL((bneck_wide_stage_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, s);
     prof_end(tok, st);
 }

@@ -69,6 +69,7 @@ struct BneckWideArgs {
 // a run of consecutive identity blocks of one stage (res4: one frame per workgroup) in ONE launch
 struct BneckStageArgs {
     int n;
+    int stagger;         // experiment (tunable STAGGER, 0 = off): cycles by which every second workgroup OF EACH XCD starts late
     BneckWideArgs blk[6];
 };
 bool bneck_stage_fusable(const BneckWideArgs& a);
