@@ -332,11 +332,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_quad_kernel(LstmFwd p) {
             }
             const float mine = q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3];
             const float pre = mine + a_cur[r];
-            const float sg = 1.0f / (1.0f + expf(-gk * pre));
+            const float sg = fast_rcp(1.0f + fast_exp(-gk * pre));
             const float act = fmaf(sg, gk, 1.0f - gk);        // lane q: gate q (i, f, g, o) of unit j
             const float gi = QuadDpp::mov<0x00>(act), gf = QuadDpp::mov<0x55>(act), gg = QuadDpp::mov<0xAA>(act), go = QuadDpp::mov<0xFF>(act);
             const float cn = fmaf(gf, c[r], gi * gg);
-            const float h = go * tanhf_(cn);
+            const float h = go * fast_tanh(cn);
             c[r] = cn;
             if (ok[r]) {
                 if (q == 0) {
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(LstmBwd p) {
             const float cprev = (s > 0) ? c_prv[r] : 0.f;
             float dh = dh_rec[r];
             if (s == s0[r]) dh += p.dhc[(size_t)nn[r] * 256 + dn[r] * HD + k];
-            const float tc = tanhf_(cc);
+            const float tc = fast_tanh(cc);
             const float dcn = fmaf(dh * go, 1.f - tc * tc, dc[r]);
             const float di = dcn * gg * gi * (1.f - gi);
             const float df = dcn * cprev * gf * (1.f - gf);

@@ -127,6 +127,12 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The recurrences' activations on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each) instead of ocml's expf
+// (range reduction) and an IEEE division (v_div_scale / Newton / v_div_fixup): ~30 of the ~300 instructions per row and step in
+// kernels that are VALU-issue-bound.  Saturation is exact (exp2(+big) = inf -> rcp = 0; exp2(-big) = 0).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * fast_rcp(fast_exp(2.0f * x) + 1.0f); }
 // branch-free tanh (ocml tanhf branches, which makes hipcc split the recurrence's fma chains across
 // basic blocks and spill W_hh): saturates correctly, |abs err| ~1e-7
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (expf(2.0f * x) + 1.0f); }
