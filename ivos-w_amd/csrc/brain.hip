@@ -355,6 +355,105 @@ __global__ __launch_bounds__(512) void lstm_fwd_quad_kernel(LstmFwd p) {
     }
 }
 
+// ---------------------------------------------------------------- forward recurrence on the 4x4x1 matrix instruction
+// The quad kernel above is VALU-bound (SQ counters: 340 VALU instructions per wave and step for two rows, 262 of them the fma
+// chains, each a 4-cycle issue; two waves per SIMD keep the VALU 76 % busy).  v_mfma_f32_4x4x1_16b_f32 computes sixteen
+// independent 4x4 outer products (K = 1) in 8 cycles: with block = hidden unit, the four B lanes of a block = that unit's four
+// gate columns (the DPP quad of the kernel above) and the four A rows = FOUR rows of the batch, one instruction does for four
+// rows what four v_fmac do for one — 128 instructions per wave and step (K = 128) for 4 rows x 64 columns against 524 fmas,
+// exact fp32 (an fma chain in k order per accumulator).  A lane keeps its column's 128 weights in registers as before; h comes
+// from LDS ([4 rows][128 + 4 pad]: lane (block, i) reads row i — four addresses per wave read, on disjoint banks); four
+// accumulators (k mod 4) break the 128-deep dependent chain.  The result layout IS the quad layout: lane (b, j) holds gate j of
+// unit b for the four rows in four registers, so activation, quad broadcast and state update are the code above per row.
+// 4 rows per workgroup: 128 workgroups for the policy pass (2B = 256 samples x 2 directions), 64 for the target: one round.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(LstmFwd p) {
+    constexpr int R = 4, HP = HD + 4;
+    __shared__ __attribute__((aligned(16))) float h_s[2][R][HP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 3, j = wave * 16 + (lane >> 2);      // gate q of hidden unit j; as an A lane: batch row q
+    float w[HD];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(p.whh + (size_t)(q * HD + j) * HD);
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+            const float4 v = wp[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    }
+    for (int i = tid; i < 2 * R * HP; i += 512) (&h_s[0][0][0])[i] = 0.f;
+    __syncthreads();
+    const float gk = (q == 2) ? 2.0f : 1.0f;
+    const int Nk = p.N - p.keep_from;
+    const int row0 = blockIdx.x * R;
+    int dd[R], nn[R];
+    bool ok[R], keep[R];
+    float c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+        ok[r] = row < 2 * p.N;
+        const int rc = ok[r] ? row : 2 * p.N - 1;
+        dd[r] = rc / p.N;
+        nn[r] = rc - dd[r] * p.N;
+        keep[r] = ok[r] && p.gates && nn[r] >= p.keep_from;
+        c[r] = 0.f;
+    }
+    float a_nx[R];
+    auto gx_fetch = [&](int s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = dd[r] ? p.T - 1 - s : s;
+            a_nx[r] = p.gx[((size_t)nn[r] * p.T + t) * 512 + q * HD + j];
+        }
+    };
+    gx_fetch(0);
+    for (int s = 0; s < p.T; ++s) {
+        const int cur = s & 1;
+        float a_cur[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a_cur[r] = a_nx[r];
+        if (s + 1 < p.T) gx_fetch(s + 1);
+        f32x4v acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        const float* hrow = &h_s[cur][q][0];                   // A operand: this lane supplies h[row q][k]
+#pragma unroll
+        for (int kc = 0; kc < HD / 4; ++kc) {
+            const float4 h4 = *reinterpret_cast<const float4*>(hrow + 4 * kc);
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.x, w[4 * kc], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.y, w[4 * kc + 1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.z, w[4 * kc + 2], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, w[4 * kc + 3], acc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = dd[r] ? p.T - 1 - s : s;
+            const float pre = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + a_cur[r];
+            const float sg = fast_rcp(1.0f + fast_exp(-gk * pre));
+            const float act = fmaf(sg, gk, 1.0f - gk);        // lane q: gate q (i, f, g, o) of unit j, batch row r
+            const float gi = QuadDpp::mov<0x00>(act), gf = QuadDpp::mov<0x55>(act), gg = QuadDpp::mov<0xAA>(act), go = QuadDpp::mov<0xFF>(act);
+            const float cn = fmaf(gf, c[r], gi * gg);
+            const float h = go * fast_tanh(cn);
+            c[r] = cn;
+            if (ok[r]) {
+                if (q == 0) {
+                    h_s[cur ^ 1][r][j] = h;
+                    p.hs[((size_t)nn[r] * p.T + t) * 256 + dd[r] * HD + j] = h;
+                }
+                if (keep[r]) {
+                    const size_t base = ((size_t)dd[r] * Nk + (nn[r] - p.keep_from)) * p.T + t;
+                    p.gates[base * 512 + q * HD + j] = act;
+                    if (q == 1) p.hprev[base * HD + j] = h_s[cur][r][j];   // h before this frame
+                    if (q == 2) p.cs[base * HD + j] = cn;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- backward recurrence (BPTT)
 struct LstmBwd {
     const float* whh;    // [512,128]
@@ -624,7 +723,9 @@ static void brain_forward_internal(const float* prm, const float* x, int N, int 
     lf.gates = b.gates; lf.cs = b.cs; lf.hprev = b.hprev;
     const int R = rows_per_wg(2 * N);
     const int nwg = (2 * N + R - 1) / R;
-    if (tune_get("LSTM_QUAD", 1)) {
+    if (tune_get("LSTM_QUAD", 1) && tune_get("LSTM_MFMA", 1) && 2 * N >= 8) {
+        hipLaunchKernelGGL(lstm_fwd_mfma_kernel, dim3((2 * N + 3) / 4), dim3(512), 0, st, lf);
+    } else if (tune_get("LSTM_QUAD", 1)) {
         if (R == 1) hipLaunchKernelGGL(lstm_fwd_quad_kernel<1>, dim3(nwg), dim3(512), 0, st, lf);
         else if (R == 2) hipLaunchKernelGGL(lstm_fwd_quad_kernel<2>, dim3(nwg), dim3(512), 0, st, lf);
         else hipLaunchKernelGGL(lstm_fwd_quad_kernel<4>, dim3(nwg), dim3(512), 0, st, lf);
