@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "gemm_f32.h"
+#include "brain_fused.h"
 
 namespace ivosw {
 
@@ -84,18 +85,20 @@ struct ColsumJob {
     float* out;          // [N]            (split over blockIdx.z: slab z at out + z * N; the caller reduces the slabs)
     float* outw;         // [N,2] when x   (slab z at outw + z * 2N)
     int M, N, ld;
+    int nsplit;          // row splits of this job (0 = gridDim.z); workgroups with blockIdx.z >= nsplit have nothing to do
 };
-struct ColsumGroup { ColsumJob j[2]; };
+struct ColsumGroup { ColsumJob j[4]; };
 __global__ __launch_bounds__(1024) void colsum_group_kernel(ColsumGroup grp) {
     __shared__ float red[3][32][33];
     const ColsumJob& jb = grp.j[blockIdx.y];
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + c;
-    if (blockIdx.x * 32 >= jb.N) return;
+    const int nsplit = jb.nsplit > 0 ? jb.nsplit : (int)gridDim.z;
+    if (blockIdx.x * 32 >= jb.N || (int)blockIdx.z >= nsplit) return;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     const bool wx = jb.x != nullptr;
     // rows [mbeg, mend) of this split (multiples of 32 rows, so every row group sees whole strides)
-    const int per = ((jb.M + (int)gridDim.z - 1) / (int)gridDim.z + 31) / 32 * 32;
+    const int per = ((jb.M + nsplit - 1) / nsplit + 31) / 32 * 32;
     const int mbeg = blockIdx.z * per, mend = min(jb.M, mbeg + per);
     if (n < jb.N) {
         int m = mbeg + rg;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_quad_kernel(LstmFwd p) {
 // 4 rows per workgroup: 128 workgroups for the policy pass (2B = 256 samples x 2 directions), 64 for the target: one round.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(LstmFwd p) {
+__device__ __forceinline__ void lstm_fwd_mfma_body(const LstmFwd& p, const int bid) {
     constexpr int R = 4, HP = HD + 4;
     __shared__ __attribute__((aligned(16))) float h_s[2][R][HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(LstmFwd p) {
     __syncthreads();
     const float gk = (q == 2) ? 2.0f : 1.0f;
     const int Nk = p.N - p.keep_from;
-    const int row0 = blockIdx.x * R;
+    const int row0 = bid * R;
     int dd[R], nn[R];
     bool ok[R], keep[R];
     float c[R];
@@ -452,6 +455,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(LstmFwd p) {
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(LstmFwd p) { lstm_fwd_mfma_body(p, blockIdx.x); }
+
+// the policy pass and the target pass of a DQN step in ONE launch (they used to run side by side on two streams, with an
+// event fork / join around them): workgroups [0, first1) run job 0, the rest job 1
+struct LstmFwdPair {
+    LstmFwd j[2];
+    int first1;
+};
+__global__ __launch_bounds__(512) void lstm_fwd_mfma_pair_kernel(LstmFwdPair pr) {
+    const int which = (int)blockIdx.x >= pr.first1;
+    lstm_fwd_mfma_body(pr.j[which], (int)blockIdx.x - (which ? pr.first1 : 0));
 }
 
 // ---------------------------------------------------------------- backward recurrence (BPTT)
@@ -702,6 +718,57 @@ static int rows_per_wg(int rows) {
     return 4;
 }
 
+// ---------------------------------------------------------------- fused forward (DQN_FUSED): three launches per pass,
+// or three launches for a policy pass AND a target pass together (see brain_fused.h)
+struct FwdPass {
+    const float* prm;
+    const float* x;      // samples [0, N0)
+    const float* x2;     // samples [N0, N) (nullptr: all from x)
+    int N, N0;
+    const FwdBufs* b;
+};
+static LstmFwd lstm_fwd_args(const FwdPass& f, int T) {
+    LstmFwd lf{};
+    lf.whh = f.prm + O_WHH; lf.gx = f.b->gx; lf.hs = f.b->hs; lf.N = f.N; lf.T = T;
+    lf.keep_from = f.b->gates ? f.b->keep_from : f.N;
+    lf.gates = f.b->gates; lf.cs = f.b->cs; lf.hprev = f.b->hprev;
+    return lf;
+}
+static bool fused_forward_ok(const FwdPass* f, int n) {
+    if (!tune_get("DQN_FUSED", 1) || !tune_get("LSTM_QUAD", 1)) return false;
+    if (n == 2) return tune_get("LSTM_MFMA", 1) && 2 * f[0].N >= 8 && 2 * f[1].N >= 8;   // the pair launch is the MFMA recurrence
+    return true;
+}
+static void brain_forward_fused(const FwdPass* f, int n, int T, hipStream_t st) {
+    EncGroup eg{};
+    DecGroup dg{};
+    int tiles[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const int rows = f[i].N * T, keep_row = f[i].b->gates ? f[i].b->keep_from * T : rows;
+        tiles[i] = (rows + FM - 1) / FM;
+        eg.j[i] = EncJob{f[i].prm, f[i].x, f[i].x2 ? f[i].x2 : f[i].x, f[i].b->gx, f[i].b->a1, f[i].b->e,
+                         f[i].x2 ? f[i].N0 * T : rows, rows, keep_row};
+        dg.j[i] = DecJob{f[i].prm, f[i].b->hs, f[i].b->d1, f[i].b->q, rows, keep_row};
+    }
+    eg.first1 = dg.first1 = tiles[0];
+    hipLaunchKernelGGL(enc_fused_kernel, dim3(tiles[0] + tiles[1]), dim3(256), 0, st, eg, O_W1, O_B1, O_W2, O_B2, O_WIH);
+    if (n == 2) {
+        LstmFwdPair pr{};
+        pr.j[0] = lstm_fwd_args(f[0], T);
+        pr.j[1] = lstm_fwd_args(f[1], T);
+        pr.first1 = (2 * f[0].N + 3) / 4;
+        hipLaunchKernelGGL(lstm_fwd_mfma_pair_kernel, dim3(pr.first1 + (2 * f[1].N + 3) / 4), dim3(512), 0, st, pr);
+    } else {
+        const LstmFwd lf = lstm_fwd_args(f[0], T);
+        const int N = f[0].N, R = rows_per_wg(2 * N), nwg = (2 * N + R - 1) / R;
+        if (tune_get("LSTM_MFMA", 1) && 2 * N >= 8) hipLaunchKernelGGL(lstm_fwd_mfma_kernel, dim3((2 * N + 3) / 4), dim3(512), 0, st, lf);
+        else if (R == 1) hipLaunchKernelGGL(lstm_fwd_quad_kernel<1>, dim3(nwg), dim3(512), 0, st, lf);
+        else if (R == 2) hipLaunchKernelGGL(lstm_fwd_quad_kernel<2>, dim3(nwg), dim3(512), 0, st, lf);
+        else hipLaunchKernelGGL(lstm_fwd_quad_kernel<4>, dim3(nwg), dim3(512), 0, st, lf);
+    }
+    hipLaunchKernelGGL(dec_fused_kernel, dim3(tiles[0] + tiles[1]), dim3(256), 0, st, dg, O_W3, O_B3, O_W4, O_B4);
+}
+
 // x2 != nullptr: samples [0, N0) come from x, [N0, N) from x2
 static void brain_forward_internal(const float* prm, const float* x, int N, int T, const FwdBufs& b, hipStream_t st,
                                    const float* x2 = nullptr, int N0 = 0) {
@@ -874,7 +941,9 @@ extern "C" int ivosw_brain_forward(const float* params, const float* x, int N, i
     hipStream_t st = as_stream(stream);
     Arena ar(ws);
     FwdBufs b = carve_fwd(ar, N, T, -1);
-    brain_forward_internal(params, x, N, T, b, st);
+    const FwdPass fp{params, x, nullptr, N, 0, &b};
+    if (fused_forward_ok(&fp, 1)) brain_forward_fused(&fp, 1, T, st);
+    else brain_forward_internal(params, x, N, T, b, st);
     (void)hipMemcpyAsync(q, b.q, (size_t)N * T * sizeof(float), hipMemcpyDeviceToDevice, st);
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
@@ -958,27 +1027,36 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
 
     // ---- forward: policy on [s'; s] in one batch, target on s' (agent.py:135-137,144); the target pass runs beside it
     // (host order matters: the policy chain is the critical path, so it is enqueued first)
-    fork(0);
-    brain_forward_internal(policy, new_state, 2 * B, T, w.pol, st, state, B);
-    brain_forward_internal(target, new_state, B, T, w.tgt, s2);
-    join(1);
-
-    // ---- head: Double-DQN targets, loss, dL/dQsa (agent.py:136-151)
+    const FwdPass passes[2] = {{policy, new_state, state, 2 * B, B, &w.pol}, {target, new_state, nullptr, B, 0, &w.tgt}};
+    const bool fused = fused_forward_ok(passes, 2);
     const float* q_np = w.pol.q;
     const float* q_s = w.pol.q + rows;
-    hipLaunchKernelGGL(dqn_head_kernel, dim3(1), dim3(256), 0, st, q_np, w.tgt.q, q_s, action, reward_step, reward_done,
-                       B, T, gamma, w.dq, loss, grads + O_B4);
-
-    // ---- decoder backward on the B rows that carry loss
     const float* d1_s = w.pol.d1 + (size_t)rows * 128;
     const float* hs_s = w.pol.hs + (size_t)rows * 256;
-    hipLaunchKernelGGL(dec_bwd_rows_kernel, dim3(B), dim3(128), 0, st, policy, w.dq, action, d1_s, hs_s, T, w.dd1c,
-                       w.w4term, w.hcc);
     GemmF32 g{};
-    // dhc[B,256] = (dd1c * W3) . (hcat > 0)
-    g.A = w.dd1c; g.sam = 128; g.sak = 1; g.B = policy + O_W3; g.sbk = 256; g.sbn = 1; g.C = w.dhc; g.ldc = 256;
-    g.M = B; g.N = 256; g.K = 128; g.mask = w.hcc; g.splitk = 1;
-    launch_gemm_f32(g, st);
+    if (fused) {
+        // both nets per launch, then head + decoder backward + dL/dh in one: 4 launches, one stream, no events
+        brain_forward_fused(passes, 2, T, st);
+        hipLaunchKernelGGL(head_fused_kernel, dim3(B), dim3(256), 0, st, policy, O_W3, O_W4, q_np, w.tgt.q, q_s, action, reward_step,
+                           reward_done, B, T, gamma, d1_s, hs_s, w.dq, w.dd1c, w.w4term, w.hcc, w.dhc, loss, grads + O_B4);
+    } else {
+        fork(0);
+        brain_forward_internal(policy, new_state, 2 * B, T, w.pol, st, state, B);
+        brain_forward_internal(target, new_state, B, T, w.tgt, s2);
+        join(1);
+
+        // ---- head: Double-DQN targets, loss, dL/dQsa (agent.py:136-151)
+        hipLaunchKernelGGL(dqn_head_kernel, dim3(1), dim3(256), 0, st, q_np, w.tgt.q, q_s, action, reward_step, reward_done,
+                           B, T, gamma, w.dq, loss, grads + O_B4);
+
+        // ---- decoder backward on the B rows that carry loss
+        hipLaunchKernelGGL(dec_bwd_rows_kernel, dim3(B), dim3(128), 0, st, policy, w.dq, action, d1_s, hs_s, T, w.dd1c,
+                           w.w4term, w.hcc);
+        // dhc[B,256] = (dd1c * W3) . (hcat > 0)
+        g.A = w.dd1c; g.sam = 128; g.sak = 1; g.B = policy + O_W3; g.sbk = 256; g.sbn = 1; g.C = w.dhc; g.ldc = 256;
+        g.M = B; g.N = 256; g.K = 128; g.mask = w.hcc; g.splitk = 1;
+        launch_gemm_f32(g, st);
+    }
 
     // ---- BPTT through the shared cell
     LstmBwd lb{};
@@ -1049,14 +1127,12 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         float* cs_b2 = slabs4;                          // [CS][128]
         float* cs_b1 = slabs4 + CS * 128;               // [CS][128]
         float* cs_w1 = slabs4 + 2 * CS * 128;           // [CS][256]
-        ColsumGroup c0{};
-        c0.j[0] = ColsumJob{w.w4term, nullptr, grads + O_W4, nullptr, B, 128, 128};
-        c0.j[1] = ColsumJob{w.dd1c, nullptr, grads + O_B3, nullptr, B, 128, 128};
-        hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 2, 1), dim3(1024), 0, st, c0);
-        ColsumGroup c1{};
-        c1.j[0] = ColsumJob{w.de, nullptr, cs_b2, nullptr, rows, 128, 128};
-        c1.j[1] = ColsumJob{w.da1, state, cs_b1, cs_w1, rows, 128, 128};
-        hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 2, CS), dim3(1024), 0, st, c1);
+        ColsumGroup c1{};                               // all four column sums in one launch (the two short ones unsplit)
+        c1.j[0] = ColsumJob{w.de, nullptr, cs_b2, nullptr, rows, 128, 128, CS};
+        c1.j[1] = ColsumJob{w.da1, state, cs_b1, cs_w1, rows, 128, 128, CS};
+        c1.j[2] = ColsumJob{w.w4term, nullptr, grads + O_W4, nullptr, B, 128, 128, 1};
+        c1.j[3] = ColsumJob{w.dd1c, nullptr, grads + O_B3, nullptr, B, 128, 128, 1};
+        hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 4, CS), dim3(1024), 0, st, c1);
         ReduceGroup rg{};
         rg.slabs[0] = slabs2; rg.out[0] = grads + O_WHH; rg.n[0] = 512 * 128; rg.nslab[0] = split_hh;
         rg.slabs[1] = slabs3; rg.out[1] = grads + O_WIH; rg.n[1] = 512 * 128; rg.nslab[1] = split_ih;

@@ -96,35 +96,57 @@ struct AdamDevState {
     double b1t, b2t;
     int step;
     float step_size, bc2_sqrt;
+    unsigned ticket;     // byte 28: workgroups of the running clamp+Adam launch that have finished (0 between launches)
 };
-__global__ void adam_tick_kernel(AdamDevState* st, float lr, float beta1, float beta2) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    AdamDevState s = *st;
-    s.step += 1;
-    // the same float64 expressions ivosw_clamp_adam evaluates on the host from its `step` argument
-    s.b1t = ipow((double)beta1, s.step);
-    s.b2t = ipow((double)beta2, s.step);
-    s.step_size = (float)((double)lr / (1.0 - s.b1t));
-    s.bc2_sqrt = (float)sqrt(1.0 - s.b2t);
-    *st = s;
-}
-__global__ void clamp_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                      float* __restrict__ v, int n, const AdamDevState* __restrict__ st, float beta1, float beta2,
-                                      float eps, float wd, float clampv, float gscale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float step_size = st->step_size, bc2_sqrt = st->bc2_sqrt;
-    float gi = g[i] * gscale;
-    gi = fminf(fmaxf(gi, -clampv), clampv);
-    const float pi = p[i];
-    gi = fmaf(wd, pi, gi);
-    float mi = m[i], vi = v[i];
-    mi = fmaf(gi - mi, 1.0f - beta1, mi);
-    vi = fmaf(1.0f - beta2, gi * gi, vi * beta2);
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
+static_assert(sizeof(AdamDevState) == 32, "AdamDevState layout (step at byte 16, ticket at byte 28)");
+
+// Clamp + Adam with the step counter advanced by the SAME launch (a one-thread tick kernel in front of it cost a link of the
+// step's launch chain, ~5 us): every thread reads the counter k left by the previous launch and evaluates step k+1's bias
+// corrections itself (the float64 expressions of ivosw_clamp_adam: identical bits); the LAST workgroup to finish — a
+// device-scope ticket, taken after the workgroup's own reads and writes — publishes k+1.  No other workgroup can still
+// be reading the state at that point, and nothing but the ticket crosses workgroups, so no fence is needed.
+template <bool VEC>
+__global__ __launch_bounds__(1024) void clamp_adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, int n, AdamDevState* __restrict__ st, float lr, float beta1,
+                                                              float beta2, float eps, float wd, float clampv, float gscale) {
+    const int step = st->step + 1;
+    const double b1t = ipow((double)beta1, step), b2t = ipow((double)beta2, step);
+    const float step_size = (float)((double)lr / (1.0 - b1t)), bc2_sqrt = (float)sqrt(1.0 - b2t);
+    auto upd = [&](float gi, float pi, float& mi, float& vi) {
+        gi = fminf(fmaxf(gi * gscale, -clampv), clampv);
+        gi = fmaf(wd, pi, gi);
+        mi = fmaf(gi - mi, 1.0f - beta1, mi);
+        vi = fmaf(1.0f - beta2, gi * gi, vi * beta2);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        return pi - step_size * (mi / denom);
+    };
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {      // 16 bytes per lane and array; the n % 4 tail elements go to the first threads
+        const int n4 = n >> 2;
+        if (t < n4) {
+            const float4 g4 = reinterpret_cast<const float4*>(g)[t];
+            float4 p4 = reinterpret_cast<float4*>(p)[t], m4 = reinterpret_cast<float4*>(m)[t], v4 = reinterpret_cast<float4*>(v)[t];
+            p4.x = upd(g4.x, p4.x, m4.x, v4.x); p4.y = upd(g4.y, p4.y, m4.y, v4.y);
+            p4.z = upd(g4.z, p4.z, m4.z, v4.z); p4.w = upd(g4.w, p4.w, m4.w, v4.w);
+            reinterpret_cast<float4*>(m)[t] = m4; reinterpret_cast<float4*>(v)[t] = v4; reinterpret_cast<float4*>(p)[t] = p4;
+        } else if (t - n4 < (n & 3)) {
+            const int i = 4 * n4 + (t - n4);
+            float mi = m[i], vi = v[i];
+            p[i] = upd(g[i], p[i], mi, vi);
+            m[i] = mi; v[i] = vi;
+        }
+    } else if (t < n) {
+        float mi = m[t], vi = v[t];
+        p[t] = upd(g[t], p[t], mi, vi);
+        m[t] = mi; v[t] = vi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+            st->b1t = b1t; st->b2t = b2t; st->step = step; st->step_size = step_size; st->bc2_sqrt = bc2_sqrt;
+            atomicExch(&st->ticket, 0u);
+        }
+    }
 }
 
 }  // namespace ivosw
@@ -140,9 +162,15 @@ extern "C" int ivosw_clamp_adam_dev(float* params, const float* grads, float* ex
     IVOSW_ON_DEVICE_OF(params);
     IVOSW_REQUIRE(n > 0, "n must be positive");
     AdamDevState* sd = static_cast<AdamDevState*>(adam_state);
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, as_stream(stream), sd, lr, beta1, beta2);
-    hipLaunchKernelGGL(clamp_adam_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), params, grads, exp_avg,
-                       exp_avg_sq, n, sd, beta1, beta2, eps, weight_decay, clamp, grad_scale);
+    // few, large workgroups: the tickets of one launch serialise on one address (708 of them took longer than the update)
+    const bool vec = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+                       reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(clamp_adam_dev_kernel<true>, dim3((n / 4 + 3 + 1023) / 1024), dim3(1024), 0, as_stream(stream), params, grads,
+                           exp_avg, exp_avg_sq, n, sd, lr, beta1, beta2, eps, weight_decay, clamp, grad_scale);
+    else
+        hipLaunchKernelGGL(clamp_adam_dev_kernel<false>, dim3((n + 1023) / 1024), dim3(1024), 0, as_stream(stream), params, grads,
+                           exp_avg, exp_avg_sq, n, sd, lr, beta1, beta2, eps, weight_decay, clamp, grad_scale);
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }

@@ -9,6 +9,7 @@
 
 namespace ivosw {
 
+int tune_get(const char* key, int dflt);   // capi.cpp
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmF32 {
@@ -297,7 +298,7 @@ inline void launch_gemm_f32_group(const GemmF32* gs, int n, hipStream_t st) {
     }
     grp.n = n;
     for (int i = n; i <= GROUP_MAX; ++i) grp.first[i] = total;
-    hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(total), dim3(256), 0, st, grp);
+    hipLaunchKernelGGL(gemm_f32_group_kernel, dim3(total), dim3(256), (size_t)tune_get("GEMM_DYNLDS", 0), st, grp);
 }
 
 }  // namespace ivosw

@@ -206,7 +206,7 @@ def test_captured_step_is_bit_identical_to_eager(dev, fused):
     idxs = [torch.from_numpy(synth.minibatch_indices(s, n=3000, B=B, seed=7)).to(dev) for s in range(6)]
     eager, cap = fresh(), fresh()
     step = CapturedDqnStep(cap, rp, B, fused=fused)
-    assert step.kernel_nodes >= 20                         # the whole launch chain sits in the graph
+    assert step.kernel_nodes >= 10                         # the whole launch chain sits in the graph
     for s, idx in enumerate(idxs):
         l0 = eager.loss_and_grads(rp.sample(idx)).clone()
         g0 = eager.policy_net.flat_grad.clone()
@@ -252,7 +252,7 @@ def test_entry_points_run_on_the_buffers_device_not_the_current_one(dev):
     assert b"not a device pointer" in L.lib().ivosw_last_error()
 
 
-@pytest.mark.parametrize("tun", [dict(LSTM_QUAD=0), dict(DQN_GROUP=0), dict(LSTM_QUAD=0, DQN_GROUP=0, DQN_STREAMS=0)])
+@pytest.mark.parametrize("tun", [dict(LSTM_QUAD=0), dict(DQN_GROUP=0), dict(DQN_FUSED=0), dict(LSTM_QUAD=0, DQN_GROUP=0, DQN_STREAMS=0)])
 def test_alternative_kernel_paths_agree_with_the_default(dev, tun):
     """The round-1 recurrences (LSTM_QUAD=0: gate column per thread, two barriers per step) and the ungrouped two-stream backward
     tail (DQN_GROUP=0) stay in the library as tunables: same step, different summation orders — loss and every gradient tensor
