@@ -12,6 +12,7 @@
 
 #include "gemm_f32.h"
 #include "brain_fused.h"
+#include "brain_bwd.h"
 
 namespace ivosw {
 
@@ -876,7 +877,7 @@ struct DqnWs {
 int tune_get(const char* key, int dflt);   // capi.cpp
 
 static constexpr int WG_SPLIT = 16;
-static constexpr int WG_SPLIT_MAX = 32;   // slab sets of the two long-K weight gradients are sized for this (tunables DQN_SPLIT_HH / _IH)
+static constexpr int WG_SPLIT_MAX = 40;   // slab sets of the two long-K weight gradients are sized for this (tunables DQN_SPLIT_HH / _IH)
 
 // One helper stream + four events per device: the only state the library keeps between calls (documented in
 // INTEGRATION.md).  Creation is serialised and all-or-nothing; ivosw_dqn_loss_grad holds the device's mutex while it
@@ -1118,11 +1119,41 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         //   2. {da1, dW2 slabs}: both read de and nothing of each other
         //   3. column sums {dW4 <- w4term, db3 <- dd1c} and, split 8 ways over the rows, {db2 <- de} {db1, dW1 <- da1 weighted by x}
         //   4. one fixed-order reduction of every slab set
-        GemmF32 g1[4] = {gde, gw[0], gw[1], gw[2]};
-        launch_gemm_f32_group(g1, 4, st);
-        gb.C = w.slabs; gb.splitk = WG_SPLIT;
-        GemmF32 g2[2] = {ga, gb};
-        launch_gemm_f32_group(g2, 2, st);
+        int split_hh_used = split_hh, split_ih_used = split_ih, split_w2_used = WG_SPLIT;
+        if (tune_get("DQN_TAIL", 1)) {
+            // register-resident kernels (brain_bwd.h): {dgrad chain de -> da1 per 16-row tile, dW_hh, dW_ih, dW3} in one launch,
+            // then dW2 (it needs de)
+            auto tiles = [](const WgradJob& j) { return (j.M / 64) * (j.N / 128) * j.nslab; };
+            TailGroup t1{};
+            t1.dg = DgradArgs{w.dG, dG_bw, policy + O_WIH, policy + O_W2, a1_s, w.de, w.da1, rows};
+            t1.n_dgrad = ((rows + 15) / 16 + 7) / 8 * 8;        // padded to a multiple of 8 (XCD-aligned weight-gradient section)
+            // K-slabs of a multiple of 48 rows where the sizes allow (the kernel's loop is unrolled by three 16-row steps)
+            auto slabs_for = [](int K, int want, int cap) {
+                const int per = std::max(48, (K / want + 47) / 48 * 48);
+                return std::min(cap, std::max(1, (K + per - 1) / per));
+            };
+            split_hh_used = slabs_for(2 * rows, 23, WG_SPLIT_MAX); split_ih_used = slabs_for(rows, 12, WG_SPLIT_MAX);   // B = 128, T = 25: 200 + 184 + 96 + 4 workgroups, one round at two per CU
+            t1.w[0] = WgradJob{w.dG, nullptr, w.pol.hprev, slabs2, 512, 128, 512, 128, 2 * rows, split_hh_used};
+            t1.w[1] = WgradJob{w.dG, dG_bw, e_s, slabs3, 512, 128, 512, 128, rows, split_ih_used};
+            t1.w[2] = WgradJob{w.dd1c, nullptr, w.hcc, grads + O_W3, 128, 256, 128, 256, B, 1};
+            t1.n = 3;
+            for (int i = 0; i < 3; ++i) t1.first[i + 1] = t1.first[i] + tiles(t1.w[i]);
+            t1.first[4] = t1.first[3];
+            hipLaunchKernelGGL(bwd_tail_kernel, dim3(t1.n_dgrad + t1.first[3]), dim3(256), 0, st, t1);
+            TailGroup t2{};
+            split_w2_used = slabs_for(rows, 32, 64);            // 48-row slabs: this launch is latency-bound, so many small workgroups
+            t2.w[0] = WgradJob{w.de, nullptr, a1_s, w.slabs, 128, 128, 128, 128, rows, split_w2_used};
+            t2.n = 1;
+            t2.first[1] = tiles(t2.w[0]);
+            for (int i = 2; i <= TAIL_MAX; ++i) t2.first[i] = t2.first[1];
+            hipLaunchKernelGGL(bwd_tail_kernel, dim3(t2.first[1]), dim3(256), 0, st, t2);
+        } else {
+            GemmF32 g1[4] = {gde, gw[0], gw[1], gw[2]};
+            launch_gemm_f32_group(g1, 4, st);
+            gb.C = w.slabs; gb.splitk = WG_SPLIT;
+            GemmF32 g2[2] = {ga, gb};
+            launch_gemm_f32_group(g2, 2, st);
+        }
         constexpr int CS = 8;                           // row splits of the two long column sums
         float* cs_b2 = slabs4;                          // [CS][128]
         float* cs_b1 = slabs4 + CS * 128;               // [CS][128]
@@ -1134,9 +1165,9 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         c1.j[3] = ColsumJob{w.dd1c, nullptr, grads + O_B3, nullptr, B, 128, 128, 1};
         hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 4, CS), dim3(1024), 0, st, c1);
         ReduceGroup rg{};
-        rg.slabs[0] = slabs2; rg.out[0] = grads + O_WHH; rg.n[0] = 512 * 128; rg.nslab[0] = split_hh;
-        rg.slabs[1] = slabs3; rg.out[1] = grads + O_WIH; rg.n[1] = 512 * 128; rg.nslab[1] = split_ih;
-        rg.slabs[2] = w.slabs; rg.out[2] = grads + O_W2; rg.n[2] = 128 * 128; rg.nslab[2] = WG_SPLIT;
+        rg.slabs[0] = slabs2; rg.out[0] = grads + O_WHH; rg.n[0] = 512 * 128; rg.nslab[0] = split_hh_used;
+        rg.slabs[1] = slabs3; rg.out[1] = grads + O_WIH; rg.n[1] = 512 * 128; rg.nslab[1] = split_ih_used;
+        rg.slabs[2] = w.slabs; rg.out[2] = grads + O_W2; rg.n[2] = 128 * 128; rg.nslab[2] = split_w2_used;
         rg.slabs[3] = cs_b2; rg.out[3] = grads + O_B2; rg.n[3] = 128; rg.nslab[3] = CS;
         rg.slabs[4] = cs_b1; rg.out[4] = grads + O_B1; rg.n[4] = 128; rg.nslab[4] = CS;
         rg.slabs[5] = cs_w1; rg.out[5] = grads + O_W1; rg.n[5] = 256; rg.nslab[5] = CS;

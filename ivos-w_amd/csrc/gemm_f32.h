@@ -248,10 +248,22 @@ struct ReduceGroup {
 __global__ void splitk_reduce_group_kernel(ReduceGroup r) {
     const int w = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r.n[w]) return;
-    const float* sl = r.slabs[w];
-    float s = 0.f;
-    for (int z = 0; z < r.nslab[w]; ++z) s += sl[(size_t)z * r.n[w] + i];
-    r.out[w][i] = s;
+    const float* sl = r.slabs[w] + i;
+    const size_t n = r.n[w];
+    const int ns = r.nslab[w];
+    // four interleaved partial sums, eight loads in flight: the plain loop was a chain of L2 round trips (12 us at 64 slabs);
+    // the order is fixed, so the result is deterministic
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = 0;
+    for (; z + 8 <= ns; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sl[(size_t)(z + u) * n];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+    }
+    for (; z < ns; ++z) s0 += sl[(size_t)z * n];
+    r.out[w][i] = (s0 + s1) + (s2 + s3);
 }
 
 // operand mode for the 16-byte path: 0 = contiguous along K, 1 = contiguous along the M / N extent, -1 = not eligible
