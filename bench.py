@@ -276,8 +276,8 @@ def build_dqn(args, rank, dev):
 
 
 def bench_dqn(args, rank, world, dev, dist, steps, warmup):
-    """One step = minibatch indices (device RNG) -> ONE hipGraphLaunch {replay gather, 3 forwards + loss + BPTT, [N=1: clamp + Adam
-    with the device-side step]} -> [N>1: RCCL all-reduce of the 724 KB gradient arena, clamp + Adam] -> host coin -> target sync."""
+    """One step = ONE hipGraphLaunch {minibatch draw (device-side counter-based generator) + replay gather, 3 forwards + loss + BPTT,
+    [N=1: clamp + Adam with the device-side step]} -> [N>1: RCCL all-reduce of the 724 KB gradient arena, clamp + Adam] -> host coin -> target sync."""
     from ivos_w_amd.models.agent import CapturedDqnStep
     agent, replay, gen = build_dqn(args, rank, dev)
     B = args.minibatch
@@ -285,7 +285,7 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     if args.dqn_eager:
         cap = None
     else:
-        cap = CapturedDqnStep(agent, replay, B, fused=fused)
+        cap = CapturedDqnStep(agent, replay, B, fused=fused, draw_seed=None if os.environ.get("IVOSW_BENCH_HOST_DRAW") else 2019 + 7919 * rank)
     nrep = len(replay)
 
     def step():
@@ -293,7 +293,8 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
             idx = torch.randint(0, nrep, (B,), device=dev, generator=gen)
             agent.loss_and_grads(replay.sample(idx))
         else:
-            torch.randint(0, nrep, (B,), device=dev, generator=gen, out=cap.idx)
+            if cap.draw is None:                # (IVOSW_BENCH_HOST_DRAW=1: the minibatch rows from torch's generator, one more launch)
+                torch.randint(0, nrep, (B,), device=dev, generator=gen, out=cap.idx)
             cap.launch()
         if world > 1:
             allreduce_grads(dist, agent.policy_net.flat_grad)
@@ -308,7 +309,8 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     per_gpu_tflops = DQN_GFLOP_PER_STEP * 1e9 * (sps / world) / 1e12
     info = {"us_per_step": round(dt / steps * 1e6, 1), "graph": cap is not None,
             "kernel_nodes_in_graph": cap.kernel_nodes if cap is not None else None,
-            "host_launches_per_step": (2 if fused else 4) if cap is not None else None,
+            "host_launches_per_step": ((1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
+            "minibatch_draw": "device (ivosw_replay_draw_gather, inside the graph)" if cap is not None and cap.draw is not None else "torch.randint",
             "roofline": {"bound": "mfma", "achieved": round(per_gpu_tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(per_gpu_tflops / PEAK_F32_TFLOPS, 5), "traffic": None,
                          "note": "whole step (10.5 GFLOP algorithmic, SURVEY 8d) / step wall time per GPU, against the fp32 MFMA peak: the step is a "

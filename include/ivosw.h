@@ -91,6 +91,19 @@ int ivosw_replay_gather(const float* old_iou, const float* new_iou, const float*
                         const float* reward_done, const int64_t* idx, int B, int T,
                         float* state, float* new_state, int64_t* action_out, float* reward_step_out,
                         float* reward_done_out, ivosw_stream_t stream);
+/* The same gather with the minibatch indices DRAWN ON THE DEVICE (uniform over [0, n) with replacement — the role of the
+ * DataLoader's shuffle, train_agent.py:177-182 — from a counter-based generator), so that a captured HIP graph of a training
+ * step needs no host-side RNG launch: draw_state is ivosw_replay_draw_state_bytes() bytes on the device {uint64 seed at byte
+ * 0, uint32 draw counter at byte 8, 4 bytes the library owns (zero)}; every call (or graph replay) uses the current counter
+ * and advances it by one.  Slot b of draw c reads row ivosw_replay_draw_index(seed, c, b, n) — the host mirror of the device
+ * arithmetic (integer only, bit-exact).  idx_out [B] int64 receives the rows that were drawn.                                */
+size_t ivosw_replay_draw_state_bytes(void);
+unsigned long long ivosw_replay_draw_index(unsigned long long seed, unsigned counter, unsigned slot, int n);
+int ivosw_replay_draw_gather(const float* old_iou, const float* new_iou, const float* annotated,
+                             const float* next_annotated, const int64_t* action, const float* reward_step,
+                             const float* reward_done, void* draw_state, int n, int B, int T, int64_t* idx_out,
+                             float* state, float* new_state, int64_t* action_out, float* reward_step_out,
+                             float* reward_done_out, ivosw_stream_t stream);
 
 /* ------------------------------------------------------------------ assessment front end ------ */
 /* Replaces (tp>0.5) + AssessNet.all2yxhw(scale=1.5) (models/assessment.py:165-166,110-161) with no D2H:

@@ -1120,6 +1120,7 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         //   3. column sums {dW4 <- w4term, db3 <- dd1c} and, split 8 ways over the rows, {db2 <- de} {db1, dW1 <- da1 weighted by x}
         //   4. one fixed-order reduction of every slab set
         int split_hh_used = split_hh, split_ih_used = split_ih, split_w2_used = WG_SPLIT;
+        bool tail_colsums_done = false;
         if (tune_get("DQN_TAIL", 1)) {
             // register-resident kernels (brain_bwd.h): {dgrad chain de -> da1 per 16-row tile, dW_hh, dW_ih, dW3} in one launch,
             // then dW2 (it needs de)
@@ -1138,7 +1139,7 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
             t1.w[2] = WgradJob{w.dd1c, nullptr, w.hcc, grads + O_W3, 128, 256, 128, 256, B, 1};
             t1.n = 3;
             for (int i = 0; i < 3; ++i) t1.first[i + 1] = t1.first[i] + tiles(t1.w[i]);
-            t1.first[4] = t1.first[3];
+            for (int i = 4; i <= TAIL_MAX; ++i) t1.first[i] = t1.first[3];
             hipLaunchKernelGGL(bwd_tail_kernel, dim3(t1.n_dgrad + t1.first[3]), dim3(256), 0, st, t1);
             TailGroup t2{};
             split_w2_used = slabs_for(rows, 32, 64);            // 48-row slabs: this launch is latency-bound, so many small workgroups
@@ -1146,7 +1147,15 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
             t2.n = 1;
             t2.first[1] = tiles(t2.w[0]);
             for (int i = 2; i <= TAIL_MAX; ++i) t2.first[i] = t2.first[1];
-            hipLaunchKernelGGL(bwd_tail_kernel, dim3(t2.first[1]), dim3(256), 0, st, t2);
+            // ... and the four column sums beside it (they used to be a launch of their own)
+            t2.cs[0] = CsumJob{w.de, nullptr, slabs4, nullptr, rows, 128, 128, 8};                                   // db2 slabs
+            t2.cs[1] = CsumJob{w.da1, state, slabs4 + 8 * 128, slabs4 + 16 * 128, rows, 128, 128, 8};                // db1, dW1 slabs
+            t2.cs[2] = CsumJob{w.w4term, nullptr, grads + O_W4, nullptr, B, 128, 128, 1};
+            t2.cs[3] = CsumJob{w.dd1c, nullptr, grads + O_B3, nullptr, B, 128, 128, 1};
+            t2.n_cs = 4;
+            for (int i = 0; i < 4; ++i) t2.cs_first[i + 1] = t2.cs_first[i] + ((t2.cs[i].N + 31) / 32) * t2.cs[i].nsplit;
+            hipLaunchKernelGGL(bwd_tail_kernel, dim3(t2.first[1] + t2.cs_first[4]), dim3(256), 0, st, t2);
+            tail_colsums_done = true;
         } else {
             GemmF32 g1[4] = {gde, gw[0], gw[1], gw[2]};
             launch_gemm_f32_group(g1, 4, st);
@@ -1158,12 +1167,14 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         float* cs_b2 = slabs4;                          // [CS][128]
         float* cs_b1 = slabs4 + CS * 128;               // [CS][128]
         float* cs_w1 = slabs4 + 2 * CS * 128;           // [CS][256]
+        if (!tail_colsums_done) {
         ColsumGroup c1{};                               // all four column sums in one launch (the two short ones unsplit)
         c1.j[0] = ColsumJob{w.de, nullptr, cs_b2, nullptr, rows, 128, 128, CS};
         c1.j[1] = ColsumJob{w.da1, state, cs_b1, cs_w1, rows, 128, 128, CS};
         c1.j[2] = ColsumJob{w.w4term, nullptr, grads + O_W4, nullptr, B, 128, 128, 1};
         c1.j[3] = ColsumJob{w.dd1c, nullptr, grads + O_B3, nullptr, B, 128, 128, 1};
         hipLaunchKernelGGL(colsum_group_kernel, dim3(4, 4, CS), dim3(1024), 0, st, c1);
+        }
         ReduceGroup rg{};
         rg.slabs[0] = slabs2; rg.out[0] = grads + O_WHH; rg.n[0] = 512 * 128; rg.nslab[0] = split_hh_used;
         rg.slabs[1] = slabs3; rg.out[1] = grads + O_WIH; rg.n[1] = 512 * 128; rg.nslab[1] = split_ih_used;

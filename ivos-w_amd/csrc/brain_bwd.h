@@ -40,13 +40,25 @@ struct DgradArgs {
     float* da1;         // [rows,128]
     int rows;
 };
+// column sums out[n] = sum_m A[m*ld + n] (bias gradients), optionally with the two sums weighted by x[m*2 + c] on top
+// (encoder_fc1's weight gradient dW1[j][c] = sum_rows da1[row][j] x[row][c] beside db1); rows split nsplit ways into slabs
+struct CsumJob {
+    const float* A;
+    const float* x;      // [M,2] or nullptr
+    float* out;          // [N]            (slab z at out + z*N)
+    float* outw;         // [N,2] when x   (slab z at outw + z*2N)
+    int M, N, ld, nsplit;
+};
 constexpr int TAIL_MAX = 4;
 struct TailGroup {
     DgradArgs dg;
     int n_dgrad;                 // workgroups [0, n_dgrad) run dgrad tiles (0: none)
     WgradJob w[TAIL_MAX];
-    int first[TAIL_MAX + 1];     // first workgroup of weight-gradient job i (after the dgrad tiles); first[n] = grid size
+    int first[TAIL_MAX + 1];     // first workgroup of weight-gradient job i (after the dgrad tiles); first[n] = their total
     int n;
+    CsumJob cs[TAIL_MAX];
+    int cs_first[TAIL_MAX + 1];  // first workgroup of column-sum job i (after the weight gradients)
+    int n_cs;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -265,6 +277,57 @@ __device__ __forceinline__ void dgrad_tile(const DgradArgs& p, int tile, float* 
     }
 }
 
+// ---------------------------------------------------------------- column-sum unit: 32 columns x one row split
+__device__ __forceinline__ void csum_unit(const CsumJob& jb, int local, float* lds) {
+    float (*red)[8][33] = reinterpret_cast<float (*)[8][33]>(lds);      // [3][8][33]
+    const int ncb = (jb.N + 31) / 32;
+    const int cb = local % ncb, z = local / ncb;
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int n = cb * 32 + c;
+    const bool wx = jb.x != nullptr;
+    const int per = ((jb.M + jb.nsplit - 1) / jb.nsplit + 7) / 8 * 8;
+    const int mbeg = z * per, mend = min(jb.M, mbeg + per);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < jb.N) {
+        int m = mbeg + rg;
+        for (; m + 56 < mend; m += 64) {        // eight loads in flight per thread, four partial sums (fixed order)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = jb.A[(size_t)(m + 8 * u) * jb.ld + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u & 3] += v[u];
+            if (wx) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float2 xv = *reinterpret_cast<const float2*>(jb.x + (size_t)(m + 8 * u) * 2);
+                    s0[u & 3] = fmaf(v[u], xv.x, s0[u & 3]);
+                    s1[u & 3] = fmaf(v[u], xv.y, s1[u & 3]);
+                }
+            }
+        }
+        for (; m < mend; m += 8) {
+            const float v = jb.A[(size_t)m * jb.ld + n];
+            s[0] += v;
+            if (wx) {
+                const float2 xv = *reinterpret_cast<const float2*>(jb.x + (size_t)m * 2);
+                s0[0] = fmaf(v, xv.x, s0[0]);
+                s1[0] = fmaf(v, xv.y, s1[0]);
+            }
+        }
+    }
+    red[0][rg][c] = (s[0] + s[1]) + (s[2] + s[3]);
+    red[1][rg][c] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+    red[2][rg][c] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+    __syncthreads();
+    if (rg < 3 && n < jb.N && (rg == 0 || wx)) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[rg][i][c];
+        if (rg == 0) jb.out[(size_t)z * jb.N + n] = t;
+        else jb.outw[(size_t)z * 2 * jb.N + n * 2 + (rg - 1)] = t;
+    }
+}
+
 // (256, 2): two workgroups per CU — the loop is bound by operand latency as much as by the matrix pipe, and with 128 accumulator
 // registers a wave still fits in 256
 __global__ __launch_bounds__(256, 2) void bwd_tail_kernel(TailGroup grp) {
@@ -277,7 +340,17 @@ __global__ __launch_bounds__(256, 2) void bwd_tail_kernel(TailGroup grp) {
     // The (M / 64) workgroups of one K-slab read the same rows of B: consecutive LOGICAL ids are made to share an XCD (the
     // hardware deals physical ids round-robin over the eight XCDs; n_dgrad is a multiple of 8), so B comes out of that XCD's
     // L2 for all but the first of them instead of crossing the fabric eight times.
-    const int wb = xcd_remap(bid - grp.n_dgrad, (int)gridDim.x - grp.n_dgrad);
+    const int n_w = grp.first[TAIL_MAX];
+    if (bid >= grp.n_dgrad + n_w) {
+        const int cbid = bid - grp.n_dgrad - n_w;
+        int q = 0;
+#pragma unroll
+        for (int i = 1; i < TAIL_MAX; ++i)
+            if (i < grp.n_cs && cbid >= grp.cs_first[i]) q = i;
+        csum_unit(grp.cs[q], cbid - grp.cs_first[q], lds);
+        return;
+    }
+    const int wb = xcd_remap(bid - grp.n_dgrad, n_w);
     int p = 0;
 #pragma unroll
     for (int i = 1; i < TAIL_MAX; ++i)

@@ -55,7 +55,7 @@ __device__ unsigned long long g_fused_probe[512][8];
 __global__ __launch_bounds__(256) void enc_fused_kernel(EncGroup grp, int o_w1, int o_b1, int o_w2, int o_b2, int o_wih) {
     __shared__ __attribute__((aligned(16))) float a_s[FM][F_LD];
     __shared__ __attribute__((aligned(16))) float e_s[FM][F_LD];
-    __shared__ float x_s[FM * 2];
+    __shared__ __attribute__((aligned(8))) float x_s[FM * 2];
     const int which = (int)blockIdx.x >= grp.first1;
     const EncJob& jb = grp.j[which];
     const int r0 = ((int)blockIdx.x - (which ? grp.first1 : 0)) * FM;
@@ -91,12 +91,17 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncGroup grp, int o_w1, 
     __syncthreads();
     FPROBE(1);
     // encoder_fc1 + relu: thread = (output unit j, row parity)
-#pragma unroll 4
-    for (int i = 0; i < FM / 2; ++i) {
-        const int r = (tid >> 7) + 2 * i;
-        const float v = fmaxf(fmaf(x_s[2 * r + 1], w11, fmaf(x_s[2 * r], w10, b1v)), 0.f);
-        a_s[r][j1] = v;
-        if (r0 + r < jb.rows && r0 + r >= jb.keep_row) jb.a1[(size_t)(r0 + r) * 128 + j1] = v;
+    {
+        float2 xr[FM / 2];          // all 24 rows' inputs first: the loop was a chain of LDS round trips (7.6 k cycles)
+#pragma unroll
+        for (int i = 0; i < FM / 2; ++i) xr[i] = *reinterpret_cast<const float2*>(&x_s[2 * ((tid >> 7) + 2 * i)]);
+#pragma unroll
+        for (int i = 0; i < FM / 2; ++i) {
+            const int r = (tid >> 7) + 2 * i;
+            const float v = fmaxf(fmaf(xr[i].y, w11, fmaf(xr[i].x, w10, b1v)), 0.f);
+            a_s[r][j1] = v;
+            if (r0 + r < jb.rows && r0 + r >= jb.keep_row) jb.a1[(size_t)(r0 + r) * 128 + j1] = v;
+        }
     }
     __syncthreads();
     FPROBE(2);

@@ -316,9 +316,13 @@ class CapturedDqnStep:
     Replaces ~40 host launches (170-250 us of enqueue per step) by one hipGraphLaunch.  The arithmetic is the eager path's:
     the same entry points are recorded, so results are bit-identical to ``Agent.loss_and_grads`` + ``optimizer.step``."""
 
-    def __init__(self, agent, replay, B, fused=True):
+    def __init__(self, agent, replay, B, fused=True, draw_seed=None):
+        """draw_seed: None = the caller writes the minibatch rows into ``self.idx`` before every launch; an integer = the rows
+        are drawn INSIDE the graph (``ivosw_replay_draw_gather``, uniform with replacement from a device-side counter-based
+        generator seeded with it), ``self.idx`` then holds the rows of the last launch."""
         dev = torch.device(agent.device)
         self.agent, self.replay, self.B, self.fused = agent, replay, B, fused
+        self.draw = replay.draw_state(draw_seed) if draw_seed is not None else None
         T = replay.T
         lib = L.lib()
         self.idx = torch.zeros(B, dtype=torch.int64, device=dev)
@@ -338,10 +342,14 @@ class CapturedDqnStep:
         with L.Graph.capture(dev) as g:
             st = L.stream_ptr(dev)
             r = replay
-            L.check(lib.ivosw_replay_gather(L.dptr(r.old_iou), L.dptr(r.new_iou), L.dptr(r.ann), L.dptr(r.next_ann),
-                                            L.dptr(r.action), L.dptr(r.reward_step), L.dptr(r.reward_done), L.dptr(self.idx), B, T,
-                                            L.dptr(self.state), L.dptr(self.new_state), L.dptr(self.action), L.dptr(self.r_step),
-                                            L.dptr(self.r_done), st), "replay_gather")
+            if self.draw is not None:
+                r.sample_drawn(B, self.draw, out=dict(idx=self.idx, state=self.state, new_state=self.new_state, action=self.action,
+                                                      reward_step=self.r_step, reward_done=self.r_done))
+            else:
+                L.check(lib.ivosw_replay_gather(L.dptr(r.old_iou), L.dptr(r.new_iou), L.dptr(r.ann), L.dptr(r.next_ann),
+                                                L.dptr(r.action), L.dptr(r.reward_step), L.dptr(r.reward_done), L.dptr(self.idx), B, T,
+                                                L.dptr(self.state), L.dptr(self.new_state), L.dptr(self.action), L.dptr(self.r_step),
+                                                L.dptr(self.r_done), st), "replay_gather")
             L.check(lib.ivosw_dqn_loss_grad(L.dptr(pn.flat), L.dptr(tn.flat), L.dptr(self.state), L.dptr(self.new_state),
                                             L.dptr(self.action), L.dptr(self.r_step), L.dptr(self.r_done), B, T,
                                             float(np.float32(agent.GAMMA)), L.dptr(pn.flat_grad), L.dptr(self.loss),

@@ -283,8 +283,26 @@ def parse_rows(frame, T=None):
     return out
 
 
+_M64 = (1 << 64) - 1
+
+
+def draw_indices(seed, counter, B, n):
+    """Host mirror of the device-side minibatch draw (``ivosw_replay_draw_gather``): the rows slot 0..B-1 of draw number
+    ``counter`` read — a splitmix64 finaliser of (seed, counter, slot) scaled to [0, n) by the high half of a 64 x 64
+    multiply.  Integer arithmetic only, so device, C host mirror (``ivosw_replay_draw_index``) and this agree bit for bit."""
+    out = np.empty(B, dtype=np.int64)
+    for b in range(B):
+        z = (seed + 0x9E3779B97F4A7C15 * (counter + 1) + 0xD1B54A32D192ED03 * (b + 1)) & _M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        z ^= z >> 31
+        out[b] = (z * n) >> 64
+    return out
+
+
 class DeviceReplay:
-    """Device-resident SoA replay buffer; ``sample(idx)`` gathers a minibatch with ``ivosw_replay_gather``."""
+    """Device-resident SoA replay buffer; ``sample(idx)`` gathers a minibatch with ``ivosw_replay_gather``,
+    ``sample_drawn`` draws the indices on the device as well (``ivosw_replay_draw_gather``)."""
 
     def __init__(self, soa, device):
         import torch
@@ -318,3 +336,31 @@ class DeviceReplay:
             L.dptr(state), L.dptr(new_state), L.dptr(act), L.dptr(rs), L.dptr(rd), L.stream_ptr(self.device)),
             "replay_gather")
         return dict(state=state, new_state=new_state, action=act, reward_step=rs, reward_done=rd)
+
+    def draw_state(self, seed, counter=0):
+        """The 16-byte device state of the on-device draw: {uint64 seed, uint32 counter, uint32 owned by the library}."""
+        import torch
+        raw = np.zeros(2, dtype=np.uint64)
+        raw[0] = np.uint64(seed & _M64)
+        raw[1] = np.uint64(counter & 0xFFFFFFFF)
+        assert self._lib.lib().ivosw_replay_draw_state_bytes() == raw.nbytes
+        return torch.from_numpy(raw.view(np.uint8).copy()).to(self.device)
+
+    def sample_drawn(self, B, draw_state, out=None):
+        """Draw B rows on the device (advancing ``draw_state``'s counter) and gather them; ``out`` = preallocated dict with
+        idx / state / new_state / action / reward_step / reward_done (what a captured graph records), else fresh tensors."""
+        import torch
+        L = self._lib
+        if out is None:
+            out = dict(idx=torch.empty(B, dtype=torch.int64, device=self.device),
+                       state=torch.empty(B, self.T, 2, dtype=torch.float32, device=self.device),
+                       new_state=torch.empty(B, self.T, 2, dtype=torch.float32, device=self.device),
+                       action=torch.empty(B, dtype=torch.int64, device=self.device),
+                       reward_step=torch.empty(B, dtype=torch.float32, device=self.device),
+                       reward_done=torch.empty(B, dtype=torch.float32, device=self.device))
+        L.check(L.lib().ivosw_replay_draw_gather(
+            L.dptr(self.old_iou), L.dptr(self.new_iou), L.dptr(self.ann), L.dptr(self.next_ann), L.dptr(self.action),
+            L.dptr(self.reward_step), L.dptr(self.reward_done), L.dptr(draw_state, torch.uint8), self.n, B, self.T,
+            L.dptr(out["idx"], torch.int64), L.dptr(out["state"]), L.dptr(out["new_state"]), L.dptr(out["action"], torch.int64),
+            L.dptr(out["reward_step"]), L.dptr(out["reward_done"]), L.stream_ptr(self.device)), "replay_draw_gather")
+        return out

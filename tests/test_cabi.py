@@ -48,6 +48,13 @@ def test_host_only_queries(handle):
     assert "conv_igemm*" in fam and "bneck*" in fam           # kernel-name patterns of the tower's contraction kernels
     assert lib.ivosw_assess_dominant_kernel(L.F32).decode() == "conv_igemm*"
     assert lib.ivosw_tune_set(b"FUSE", 1) == 0 and lib.ivosw_tune_set(None, 1) != 0
+    # the minibatch draw's host mirrors (C and Python) are the same integer function
+    from ivos_w_amd.models.momory_pool import draw_indices
+    assert lib.ivosw_replay_draw_state_bytes() == 16
+    for seed, counter, n in ((0, 0, 1), (2019, 0, 50000), (0xFFFF_FFFF_FFFF_FFFF, 0xFFFF_FFFF, 3000), (0x1234_5678_9ABC_DEF1, 77, 2 ** 31 - 1)):
+        py = draw_indices(seed, counter, 40, n)
+        assert py.min() >= 0 and py.max() < n
+        assert [int(lib.ivosw_replay_draw_index(seed, counter, b, n)) for b in range(40)] == [int(v) for v in py]
 
 
 def test_argument_errors_do_not_touch_the_gpu(handle):

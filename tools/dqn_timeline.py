@@ -12,7 +12,7 @@ cols = [r[1] for r in c.execute(f"pragma table_info({ks})")]
 namecol = "kernel_name" if "kernel_name" in cols else "display_name"
 rows = c.execute(f"select k.{namecol}, d.start, d.end, d.grid_size_x, d.workgroup_size_x, d.grid_size_y, d.grid_size_z, d.queue_id, d.stream_id "
                  f"from {kd} d join {ks} k on d.kernel_id = k.id order by d.start").fetchall()
-idx = [i for i, r in enumerate(rows) if "replay_gather" in r[0]]
+idx = [i for i, r in enumerate(rows) if "replay_gather" in r[0] or "replay_draw_gather" in r[0]]
 a, b = idx[-3], idx[-2]
 t0 = rows[a][1]
 busy_end = t0
