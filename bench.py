@@ -303,13 +303,35 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
             agent.optimizer.step()
         if np.random.random() < agent.update_rate:
             agent.sync_target()
-    dt = timed(step, steps, warmup, dev, dist, min(args.min_warm_s, 0.5))
+    loop = None
+    if cap is not None and fused and cap.draw is not None and args.dqn_block > 1:
+        # N = 1: the same steps in blocks of `dqn_block` per hipGraphLaunch whenever no target-sync coin of the block fires
+        # (GraphedDqnLoop: same coin stream, same minibatch stream, bit-identical results; an 8.7 us bubble separates two
+        # graph launches).  Timed like `timed()`: warm-up, synchronize, EXACTLY `steps` steps, synchronize.
+        from ivos_w_amd.models.agent import GraphedDqnLoop
+        loop = GraphedDqnLoop(agent, replay, B, draw_seed=2019 + 7919 * rank, block=args.dqn_block)
+        cap = loop.one
+        t_w = time.perf_counter()
+        loop.run(warmup)
+        torch.cuda.synchronize(dev)
+        while time.perf_counter() - t_w < min(args.min_warm_s, 0.5):
+            loop.run(max(1, warmup))
+            torch.cuda.synchronize(dev)
+        l0 = loop.launches
+        t0 = time.perf_counter()
+        loop.run(steps)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        launches_per_step = (loop.launches - l0) / steps
+    else:
+        dt = timed(step, steps, warmup, dev, dist, min(args.min_warm_s, 0.5))
     assert torch.isfinite(agent.policy_net.flat).all() and agent.optimizer.state["step"] >= steps + warmup
     sps = world * steps / dt
     per_gpu_tflops = DQN_GFLOP_PER_STEP * 1e9 * (sps / world) / 1e12
     info = {"us_per_step": round(dt / steps * 1e6, 1), "graph": cap is not None,
             "kernel_nodes_in_graph": cap.kernel_nodes if cap is not None else None,
-            "host_launches_per_step": ((1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
+            "host_launches_per_step": (round(launches_per_step, 3) if loop is not None else (1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
+            "steps_per_graph_launch": args.dqn_block if loop is not None else (1 if cap is not None else None),
             "minibatch_draw": "device (ivosw_replay_draw_gather, inside the graph)" if cap is not None and cap.draw is not None else "torch.randint",
             "roofline": {"bound": "mfma", "achieved": round(per_gpu_tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(per_gpu_tflops / PEAK_F32_TFLOPS, 5), "traffic": None,
@@ -506,6 +528,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=128)
     ap.add_argument("--replay", type=int, default=50000)
     ap.add_argument("--dqn-steps", type=int, default=2000)
+    ap.add_argument("--dqn-block", type=int, default=8, help="N = 1: training steps per hipGraphLaunch when no target-sync coin of the block fires (1 = one graph launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-report", default="", help="write a per-conv-layer timing table (HIP events) to this file")
     args = ap.parse_args()

@@ -298,6 +298,20 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const float* __restrict
     const int b = blockIdx.x, tid = threadIdx.x;
     int a = (int)action[b];
     a = min(max(a, 0), T - 1);
+    // Everything that does not depend on the argmax is requested up front (the kernel is a chain of L2 round trips
+    // otherwise): this thread's column of W3 (128 registers), the loss row of d1 / h, the scalars of the targets.
+    float w3c[128];
+    {
+        const float* w = prm + o_w3 + tid;
+#pragma unroll
+        for (int j = 0; j < 128; ++j) w3c[j] = w[(size_t)j * 256];
+    }
+    const size_t row = (size_t)b * T + a;
+    const float hv = hs_s[row * 256 + tid];
+    const float d1v = tid < 128 ? d1_s[row * 128 + tid] : 0.f;
+    const float w4v = tid < 128 ? prm[o_w4 + tid] : 0.f;
+    const float rs = r_step[b], rd = r_done[b], qsa = q_s[(size_t)b * T + a];
+    __builtin_amdgcn_sched_barrier(0);
     if (tid < 64) {
         const float* qp = q_np + (size_t)b * T;
         float best = -INFINITY;
@@ -314,9 +328,8 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const float* __restrict
         }
         if (tid == 0) {
             const float qn = q_nt[(size_t)b * T + am];
-            const float y1 = qn * gamma + r_step[b] * 0.1f;
-            const float y2 = r_done[b] * 0.1f;
-            const float qsa = q_s[(size_t)b * T + a];
+            const float y1 = qn * gamma + rs * 0.1f;
+            const float y2 = rd * 0.1f;
             const float e1 = qsa - y1, e2 = qsa - y2;
             const float d = (2.0f / (float)B) * (e1 + e2);
             d_sh = d;
@@ -325,26 +338,23 @@ __global__ __launch_bounds__(256) void head_fused_kernel(const float* __restrict
     }
     __syncthreads();
     const float d = d_sh;
-    const size_t row = (size_t)b * T + a;
     if (tid < 128) {
-        const float v = d1_s[row * 128 + tid];
-        w4term[(size_t)b * 128 + tid] = d * v;
-        const float dd = (v > 0.f) ? d * prm[o_w4 + tid] : 0.f;
+        w4term[(size_t)b * 128 + tid] = d * d1v;
+        const float dd = (d1v > 0.f) ? d * w4v : 0.f;
         dd1c[(size_t)b * 128 + tid] = dd;
         dd_s[tid] = dd;
     }
-    const float h = fmaxf(hs_s[row * 256 + tid], 0.f);
+    const float h = fmaxf(hv, 0.f);
     hcc[(size_t)b * 256 + tid] = h;
     __syncthreads();
     {
-        const float* w = prm + o_w3 + tid;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
+#pragma unroll
         for (int j = 0; j < 128; j += 4) {
-            a0 = fmaf(dd_s[j], w[(size_t)j * 256], a0);
-            a1 = fmaf(dd_s[j + 1], w[(size_t)(j + 1) * 256], a1);
-            a2 = fmaf(dd_s[j + 2], w[(size_t)(j + 2) * 256], a2);
-            a3 = fmaf(dd_s[j + 3], w[(size_t)(j + 3) * 256], a3);
+            a0 = fmaf(dd_s[j], w3c[j], a0);
+            a1 = fmaf(dd_s[j + 1], w3c[j + 1], a1);
+            a2 = fmaf(dd_s[j + 2], w3c[j + 2], a2);
+            a3 = fmaf(dd_s[j + 3], w3c[j + 3], a3);
         }
         dhc[(size_t)b * 256 + tid] = (h > 0.f) ? (a0 + a1) + (a2 + a3) : 0.f;
     }

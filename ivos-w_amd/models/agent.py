@@ -316,13 +316,19 @@ class CapturedDqnStep:
     Replaces ~40 host launches (170-250 us of enqueue per step) by one hipGraphLaunch.  The arithmetic is the eager path's:
     the same entry points are recorded, so results are bit-identical to ``Agent.loss_and_grads`` + ``optimizer.step``."""
 
-    def __init__(self, agent, replay, B, fused=True, draw_seed=None):
+    def __init__(self, agent, replay, B, fused=True, draw_seed=None, steps=1, draw_state=None):
         """draw_seed: None = the caller writes the minibatch rows into ``self.idx`` before every launch; an integer = the rows
         are drawn INSIDE the graph (``ivosw_replay_draw_gather``, uniform with replacement from a device-side counter-based
-        generator seeded with it), ``self.idx`` then holds the rows of the last launch."""
+        generator seeded with it), ``self.idx`` then holds the rows of the last launch.  draw_state: share another captured
+        step's generator state instead of creating one.  steps > 1 (needs the in-graph draw and fused=True): that many
+        consecutive training steps per launch — everything a step changes (parameters, Adam moments and step counter, draw
+        counter) lives on the device, so the recorded sequence simply repeats; the caller owns the host-side coin of the
+        target sync, i.e. launches a multi-step graph only over steps whose coins do not fire (``GraphedDqnLoop``)."""
         dev = torch.device(agent.device)
-        self.agent, self.replay, self.B, self.fused = agent, replay, B, fused
-        self.draw = replay.draw_state(draw_seed) if draw_seed is not None else None
+        self.agent, self.replay, self.B, self.fused, self.steps = agent, replay, B, fused, int(steps)
+        self.draw = draw_state if draw_state is not None else (replay.draw_state(draw_seed) if draw_seed is not None else None)
+        if self.steps > 1 and (self.draw is None or not fused):
+            raise ValueError("a multi-step graph needs the in-graph minibatch draw and the fused clamp + Adam")
         T = replay.T
         lib = L.lib()
         self.idx = torch.zeros(B, dtype=torch.int64, device=dev)
@@ -340,6 +346,7 @@ class CapturedDqnStep:
         self._keys = (pn.flat.data_ptr(), tn.flat.data_ptr(), pn.flat_grad.data_ptr())
         torch.cuda.synchronize(dev)
         with L.Graph.capture(dev) as g:
+          for _ in range(self.steps):
             st = L.stream_ptr(dev)
             r = replay
             if self.draw is not None:
@@ -368,5 +375,41 @@ class CapturedDqnStep:
             a.optimizer.dev_state()              # resync if an eager step ran in between
         self.graph.launch()
         if self.fused:
-            a.optimizer.note_dev_steps(1)
+            a.optimizer.note_dev_steps(self.steps)
         return self.loss
+
+
+class GraphedDqnLoop:
+    """The training loop of train_agent.py:177-182 / Agent.update_agent (models/agent.py:103-166) on captured graphs:
+    every step = draw a minibatch, update the policy net, flip the reference's target-sync coin (``np.random.random() <
+    update_rate``, one coin per step, in step order).  Steps are launched ``block`` at a time as ONE hipGraphLaunch whenever
+    none of the block's coins fires (an 8.7 us bubble separates consecutive graph launches: per step it is 1/block of that);
+    a block with a firing coin runs step by step with the sync where the reference has it.  Same coin stream, same minibatch
+    stream (device counter), same arithmetic: results equal the step-by-step loop's bit for bit."""
+
+    def __init__(self, agent, replay, B, draw_seed, block=8):
+        self.agent, self.block = agent, int(block)
+        self.one = CapturedDqnStep(agent, replay, B, fused=True, draw_seed=draw_seed)
+        self.many = CapturedDqnStep(agent, replay, B, fused=True, draw_state=self.one.draw, steps=self.block) if self.block > 1 else None
+        self.launches = 0
+        self.syncs = 0
+
+    def run(self, n):
+        """n training steps; returns the device loss tensor of the last one."""
+        a = self.agent
+        done, loss = 0, None
+        while done < n:
+            k = min(self.block, n - done)
+            coins = np.random.random(k) < a.update_rate            # the same draws, in the same order, as k scalar calls
+            if k == self.block and self.many is not None and not coins.any():
+                loss = self.many.launch()
+                self.launches += 1
+            else:
+                for c in coins:
+                    loss = self.one.launch()
+                    self.launches += 1
+                    if c:
+                        a.sync_target()
+                        self.syncs += 1
+            done += k
+        return loss

@@ -215,6 +215,43 @@ def test_device_side_minibatch_draw(dev):
         assert torch.equal(eager.policy_net.flat, cap.policy_net.flat), c
 
 
+def test_blocked_graph_loop_equals_the_step_by_step_loop(dev):
+    """GraphedDqnLoop (8 steps per hipGraphLaunch when no target-sync coin of the block fires) against single-step launches with
+    the coin after every step: same np.random coin stream, same device-side minibatch stream -> identical parameters, target
+    net, Adam state and number of syncs, bit for bit; both kinds of block must have occurred."""
+    from ivos_w_amd.models.agent import Agent, CapturedDqnStep, GraphedDqnLoop
+    from ivos_w_amd.models.momory_pool import DeviceReplay
+    tr = synth.replay_transitions(n=3000, T=25, seed=11)
+    rp = DeviceReplay(tr, dev)
+    B, seed, n = 64, 99, 61
+
+    def fresh():
+        a = Agent(dev, cfg(update_rate=0.05))
+        load_brain(a.policy_net, 0)
+        load_brain(a.target_net, 1)
+        return a
+    ref, blk = fresh(), fresh()
+    np.random.seed(5)
+    one = CapturedDqnStep(ref, rp, B, fused=True, draw_seed=seed)
+    syncs = 0
+    for _ in range(n):
+        one.launch()
+        if np.random.random() < ref.update_rate:
+            ref.sync_target()
+            syncs += 1
+    np.random.seed(5)
+    loop = GraphedDqnLoop(blk, rp, B, draw_seed=seed, block=8)
+    loop.run(40)
+    loop.run(n - 40)
+    assert loop.syncs == syncs and 0 < syncs
+    assert n // 8 <= loop.launches < n                   # some blocks went out as one launch, some step by step
+    assert blk.optimizer.state["step"] == ref.optimizer.state["step"] == n
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(blk.optimizer.state[k], ref.optimizer.state[k]), k
+    assert torch.equal(blk.policy_net.flat, ref.policy_net.flat) and torch.equal(blk.target_net.flat, ref.target_net.flat)
+    assert torch.equal(loop.one.loss, one.loss)
+
+
 def test_update_agent_none(dev, capsys):
     from ivos_w_amd.models.agent import Agent
     assert Agent(dev, cfg()).update_agent(None) is None
