@@ -207,6 +207,10 @@ int ivosw_tune_set(const char* key, int value);
 /* 1 when the library was built with -DIVOSW_ABLATION=1 (the ablation switches IVOSW_DEBUG_CONV / BDBG are compiled in and can
  * skip MFMAs, loads or stores); the default build returns 0 and contains none of them.  bench.py refuses to run on 1.   */
 int ivosw_ablation_build(void);
+/* Tuning probe: the fused Brain forwards that follow stamp s_memtime at four points (step start, MFMAs done, state update
+ * done, barrier passed) of recurrence step T/2 (slots 0-3) and at kernel entry / weights in registers / last step done (4-6),
+ * per workgroup, into ts [workgroups,8] uint64 (device); NULL = off.                                                     */
+int ivosw_lstm_probe(unsigned long long* ts);
 /* Tuning probe: ONE fused bottleneck (wd/bd NULL: identity block, else the stride-1 downsample block)
  * (x [B,H,W,Cin] bf16 -> y [B,H,W,4*Cmid] bf16; weights packed
  * K-major bf16 with fp32 biases as ivosw_assess_pack lays them out) with s_memtime stamps at the phase

@@ -156,6 +156,7 @@ struct LstmFwd {
     float* hprev;      // [2,N,T,128] h before consuming frame t (nullable)
     int N, T;
     int keep_from;     // samples >= keep_from store gates/cs/hprev
+    unsigned long long* ts;   // phase probe (ivosw_lstm_probe, tools/lstm_probe.py): s_memtime stamps of step T/2 per workgroup, or nullptr
 };
 
 template <int R>
@@ -376,7 +377,11 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmFwd& p, const int b
     constexpr int R = 4, HP = HD + 4;
     __shared__ __attribute__((aligned(16))) float h_s[2][R][HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (p.ts && tid == 0) p.ts[(size_t)bid * 8 + 4] = __builtin_amdgcn_s_memtime();
     const int q = lane & 3, j = wave * 16 + (lane >> 2);      // gate q of hidden unit j; as an A lane: batch row q
+    // (tried: the wave's rows through coalesced 8-KB reads + a wave-local LDS transpose instead of one row per lane — 18.1 k
+    // against 15.9 k cycles for these loads: what they wait for is 256 KB per workgroup out of L2 lines that all 192
+    // workgroups want at the same moment, not the access pattern)
     float w[HD];
     {
         const float4* wp = reinterpret_cast<const float4*>(p.whh + (size_t)(q * HD + j) * HD);
@@ -413,12 +418,15 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmFwd& p, const int b
         }
     };
     gx_fetch(0);
+    if (p.ts && tid == 0) p.ts[(size_t)bid * 8 + 5] = __builtin_amdgcn_s_memtime() + (unsigned long long)(w[0] == 1.2345e33f);
     for (int s = 0; s < p.T; ++s) {
         const int cur = s & 1;
         float a_cur[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) a_cur[r] = a_nx[r];
         if (s + 1 < p.T) gx_fetch(s + 1);
+        const bool probe = p.ts && tid == 0 && s == p.T / 2;
+        if (probe) p.ts[(size_t)bid * 8 + 0] = __builtin_amdgcn_s_memtime();
         f32x4v acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -431,6 +439,9 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmFwd& p, const int b
             acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.z, w[4 * kc + 2], acc[2], 0, 0, 0);
             acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, w[4 * kc + 3], acc[3], 0, 0, 0);
         }
+        if (probe) p.ts[(size_t)bid * 8 + 1] = __builtin_amdgcn_s_memtime() + (unsigned long long)(acc[0][0] == 1.2345e33f);   // (waits for the MFMAs)
+        // (VALU-throughput-bound with two waves per SIMD — ~650 issue cycles each, 16 transcendentals at quarter rate among
+        // them — not latency-bound: computing the four rows as one branch-free block ahead of the stores changed nothing)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int t = dd[r] ? p.T - 1 - s : s;
@@ -454,8 +465,11 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmFwd& p, const int b
                 }
             }
         }
+        if (probe) p.ts[(size_t)bid * 8 + 2] = __builtin_amdgcn_s_memtime();
         __syncthreads();
+        if (probe) p.ts[(size_t)bid * 8 + 3] = __builtin_amdgcn_s_memtime();
     }
+    if (p.ts && tid == 0) p.ts[(size_t)bid * 8 + 6] = __builtin_amdgcn_s_memtime();
 }
 
 __global__ __launch_bounds__(512) void lstm_fwd_mfma_kernel(LstmFwd p) { lstm_fwd_mfma_body(p, blockIdx.x); }
@@ -728,8 +742,10 @@ struct FwdPass {
     int N, N0;
     const FwdBufs* b;
 };
+static unsigned long long* g_lstm_probe = nullptr;     // set by ivosw_lstm_probe (tuning aid; never in a product call path)
 static LstmFwd lstm_fwd_args(const FwdPass& f, int T) {
     LstmFwd lf{};
+    lf.ts = g_lstm_probe;
     lf.whh = f.prm + O_WHH; lf.gx = f.b->gx; lf.hs = f.b->hs; lf.N = f.N; lf.T = T;
     lf.keep_from = f.b->gates ? f.b->keep_from : f.N;
     lf.gates = f.b->gates; lf.cs = f.b->cs; lf.hprev = f.b->hprev;
@@ -1208,5 +1224,12 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         return IVOSW_ERR_LAUNCH;
     }
     IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+/* Tuning probe: subsequent fused forwards stamp s_memtime at four points of recurrence step T/2 per workgroup into ts
+ * ([workgroups, 8] uint64 on the device: 0-3 the step's four points, 4 kernel entry, 5 weights in registers, 6 last step done; NULL switches the probe off).  tools/lstm_probe.py. */
+extern "C" int ivosw_lstm_probe(unsigned long long* ts) {
+    g_lstm_probe = ts;
     return IVOSW_OK;
 }
