@@ -958,30 +958,38 @@ extern "C" int ivosw_brain_forward(const float* params, const float* x, int N, i
     hipStream_t st = as_stream(stream);
     Arena ar(ws);
     FwdBufs b = carve_fwd(ar, N, T, -1);
+    b.q = q;                              // the decoder writes the caller's buffer (a device-to-device copy was a launch of its own)
     const FwdPass fp{params, x, nullptr, N, 0, &b};
     if (fused_forward_ok(&fp, 1)) brain_forward_fused(&fp, 1, T, st);
     else brain_forward_internal(params, x, N, T, b, st);
-    (void)hipMemcpyAsync(q, b.q, (size_t)N * T * sizeof(float), hipMemcpyDeviceToDevice, st);
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
 
-__global__ void argmax_rows_kernel(const float* __restrict__ q, int N, int T, int64_t* __restrict__ idx) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// first maximum of each row (numpy / torch-CPU argmax): one wave per row, lanes stride the frames, ties go to the lower index
+__global__ __launch_bounds__(64) void argmax_rows_kernel(const float* __restrict__ q, int N, int T, int64_t* __restrict__ idx) {
+    const int n = blockIdx.x, lane = threadIdx.x;
     const float* r = q + (size_t)n * T;
-    int am = 0;
-    float best = r[0];
-    for (int t = 1; t < T; ++t)
-        if (r[t] > best) { best = r[t]; am = t; }
-    idx[n] = am;
+    float best = -INFINITY;
+    int am = 0x7fffffff;
+    for (int t = lane; t < T; t += 64) {
+        const float v = r[t];
+        if (v > best || am == 0x7fffffff) { best = v; am = t; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (oa != 0x7fffffff && (am == 0x7fffffff || ob > best || (ob == best && oa < am))) { best = ob; am = oa; }
+    }
+    if (lane == 0) idx[n] = am;
 }
 
 extern "C" int ivosw_brain_argmax(const float* q, int N, int T, int64_t* idx, ivosw_stream_t stream) {
     IVOSW_REQUIRE(q && idx, "null pointer");
     IVOSW_ON_DEVICE_OF(idx);
     IVOSW_REQUIRE(N > 0 && T > 0, "N and T must be positive");
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((N + 63) / 64), dim3(64), 0, as_stream(stream), q, N, T, idx);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(N), dim3(64), 0, as_stream(stream), q, N, T, idx);
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }

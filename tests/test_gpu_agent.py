@@ -153,6 +153,21 @@ def test_three_update_steps_vs_reference_golden(dev, golden_dir, B):
     assert abs(agent.get_avg_loss() - np.mean([g[f"loss_B{B}_s{s}"] for s in range(3)])) < 1e-5
 
 
+@pytest.mark.parametrize("T", [1, 7, 63, 64, 65, 200])
+def test_argmax_rows_first_maximum_with_ties(dev, T):
+    """ivosw_brain_argmax = numpy's argmax (first maximum) for any row length, ties included (one wave per row, lanes stride
+    the frames and the wave reduction prefers the lower index)."""
+    from ivos_w_amd import _lib as L
+    rs = np.random.RandomState(T)
+    q = rs.randint(0, 4, size=(9, T)).astype(np.float32)          # few distinct values: many ties
+    q[3] = -1e30
+    q[4, -1] = 7.0
+    tq = torch.from_numpy(q).to(dev)
+    idx = torch.empty(9, dtype=torch.int64, device=dev)
+    L.check(L.lib().ivosw_brain_argmax(L.dptr(tq), 9, T, L.dptr(idx, torch.int64), L.stream_ptr(dev)), "argmax")
+    np.testing.assert_array_equal(idx.cpu().numpy(), q.argmax(1))
+
+
 def test_replay_gather_and_device_step(dev):
     from ivos_w_amd.models.agent import Agent
     from ivos_w_amd.models.momory_pool import DeviceReplay
