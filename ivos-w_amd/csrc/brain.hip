@@ -409,6 +409,16 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmFwd& p, const int b
         keep[r] = ok[r] && p.gates && nn[r] >= p.keep_from;
         c[r] = 0.f;
     }
+    // After the gate activations a 4 x 4 transpose inside the quad hands lane q the four gates of batch row q, so the cell
+    // update (two of the four transcendentals per element, the state register, the h / c stores) is done ONCE per (unit, row)
+    // by that lane instead of by every lane of the quad for every row: 64 VALU instructions (10 transcendental) per step and
+    // lane instead of 88 (16) in a phase that is VALU-throughput-bound.  This lane's row:
+    const bool my_ok = q == 0 ? ok[0] : q == 1 ? ok[1] : q == 2 ? ok[2] : ok[3];
+    const bool my_keep = q == 0 ? keep[0] : q == 1 ? keep[1] : q == 2 ? keep[2] : keep[3];
+    const int my_d = q == 0 ? dd[0] : q == 1 ? dd[1] : q == 2 ? dd[2] : dd[3];
+    const int my_n = q == 0 ? nn[0] : q == 1 ? nn[1] : q == 2 ? nn[2] : nn[3];
+    const bool q_odd = (q & 1) != 0, q_hi = (q & 2) != 0;
+    float cq = 0.f;                                            // cell state of (unit j, row q)
     float a_nx[R];
     auto gx_fetch = [&](int s) {
 #pragma unroll
@@ -431,38 +441,69 @@ __device__ __forceinline__ void lstm_fwd_mfma_body(const LstmFwd& p, const int b
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
         const float* hrow = &h_s[cur][q][0];                   // A operand: this lane supplies h[row q][k]
+        // h in four batches of eight 16-byte reads, a batch ahead of the MFMAs that use it (left to itself hipcc keeps two reads
+        // in flight: ~70 cycles of MFMAs against an LDS round trip of twice that)
+        float4 hb[2][8];
 #pragma unroll
-        for (int kc = 0; kc < HD / 4; ++kc) {
-            const float4 h4 = *reinterpret_cast<const float4*>(hrow + 4 * kc);
-            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.x, w[4 * kc], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.y, w[4 * kc + 1], acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.z, w[4 * kc + 2], acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, w[4 * kc + 3], acc[3], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) hb[0][i] = *reinterpret_cast<const float4*>(hrow + 4 * i);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hb[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(hrow + 4 * (8 * (g + 1) + i));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kc = 8 * g + i;
+                const float4 h4 = hb[g & 1][i];
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.x, w[4 * kc], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.y, w[4 * kc + 1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.z, w[4 * kc + 2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, w[4 * kc + 3], acc[3], 0, 0, 0);
+            }
         }
         if (probe) p.ts[(size_t)bid * 8 + 1] = __builtin_amdgcn_s_memtime() + (unsigned long long)(acc[0][0] == 1.2345e33f);   // (waits for the MFMAs)
         // (VALU-throughput-bound with two waves per SIMD — ~650 issue cycles each, 16 transcendentals at quarter rate among
         // them — not latency-bound: computing the four rows as one branch-free block ahead of the stores changed nothing)
+        float m0[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int t = dd[r] ? p.T - 1 - s : s;
             const float pre = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + a_cur[r];
             const float sg = fast_rcp(1.0f + fast_exp(-gk * pre));
-            const float act = fmaf(sg, gk, 1.0f - gk);        // lane q: gate q (i, f, g, o) of unit j, batch row r
-            const float gi = QuadDpp::mov<0x00>(act), gf = QuadDpp::mov<0x55>(act), gg = QuadDpp::mov<0xAA>(act), go = QuadDpp::mov<0xFF>(act);
-            const float cn = fmaf(gf, c[r], gi * gg);
-            const float h = go * fast_tanh(cn);
-            c[r] = cn;
-            if (ok[r]) {
-                if (q == 0) {
-                    h_s[cur ^ 1][r][j] = h;
-                    p.hs[((size_t)nn[r] * p.T + t) * 256 + dd[r] * HD + j] = h;
-                }
-                if (keep[r]) {
-                    const size_t base = ((size_t)dd[r] * Nk + (nn[r] - p.keep_from)) * p.T + t;
-                    p.gates[base * 512 + q * HD + j] = act;
-                    if (q == 1) p.hprev[base * HD + j] = h_s[cur][r][j];   // h before this frame
-                    if (q == 2) p.cs[base * HD + j] = cn;
-                }
+            m0[r] = fmaf(sg, gk, 1.0f - gk);                  // lane q: gate q (i, f, g, o) of unit j, batch row r
+        }
+        // transpose: m2[k] of lane q = gate k of row q (2 x 2 blocks across lane ^ 1, then blocks across lane ^ 2)
+        float m1[R], m2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float x = QuadDpp::mov<0xB1>(m0[r ^ 1]);     // quad_perm [1,0,3,2]
+            m1[r] = (((r & 1) != 0) == q_odd) ? m0[r] : x;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float x = QuadDpp::mov<0x4E>(m1[r ^ 2]);     // quad_perm [2,3,0,1]
+            m2[r] = (((r & 2) != 0) == q_hi) ? m1[r] : x;
+        }
+        cq = fmaf(m2[1], cq, m2[0] * m2[2]);
+        const float hq = m2[3] * fast_tanh(cq);
+        const int tq = my_d ? p.T - 1 - s : s;
+        if (my_ok) {
+            const float hold = h_s[cur][q][j];                 // h before this frame
+            h_s[cur ^ 1][q][j] = hq;
+            p.hs[((size_t)my_n * p.T + tq) * 256 + my_d * HD + j] = hq;
+            if (my_keep) {
+                const size_t base = ((size_t)my_d * Nk + (my_n - p.keep_from)) * p.T + tq;
+                p.hprev[base * HD + j] = hold;
+                p.cs[base * HD + j] = cq;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (keep[r]) {
+                const int t = dd[r] ? p.T - 1 - s : s;
+                const size_t base = ((size_t)dd[r] * Nk + (nn[r] - p.keep_from)) * p.T + t;
+                p.gates[base * 512 + q * HD + j] = m0[r];
             }
         }
         if (probe) p.ts[(size_t)bid * 8 + 2] = __builtin_amdgcn_s_memtime();
