@@ -210,7 +210,7 @@ int ivosw_ablation_build(void);
 /* Tuning probe: the fused Brain forwards that follow stamp s_memtime at four points (step start, MFMAs done, state update
  * done, barrier passed) of recurrence step T/2 (slots 0-3) and at kernel entry / weights in registers / last step done (4-6),
  * per workgroup, into ts [workgroups,8] uint64 (device); NULL = off.                                                     */
-int ivosw_lstm_probe(unsigned long long* ts);
+int ivosw_lstm_probe(unsigned long long* ts, unsigned long long* ts_bwd);   /* ts_bwd: the same for the BPTT kernel of ivosw_dqn_loss_grad */
 /* Tuning probe: ONE fused bottleneck (wd/bd NULL: identity block, else the stride-1 downsample block)
  * (x [B,H,W,Cin] bf16 -> y [B,H,W,4*Cmid] bf16; weights packed
  * K-major bf16 with fp32 biases as ivosw_assess_pack lays them out) with s_memtime stamps at the phase

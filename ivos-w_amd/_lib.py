@@ -30,7 +30,7 @@ SIGNATURES = {
     "ivosw_clamp_adam_dev": (_i, [_p, _p, _p, _p, _i, _p, _f, _f, _f, _f, _f, _f, _f, _p]),
     "ivosw_copy_f32": (_i, [_p, _p, _sz, _p]),
     "ivosw_replay_gather": (_i, [_p] * 8 + [_i, _i] + [_p] * 5 + [_p]),
-    "ivosw_lstm_probe": (_i, [_p]),
+    "ivosw_lstm_probe": (_i, [_p, _p]),
     "ivosw_replay_draw_state_bytes": (_sz, []),
     "ivosw_replay_draw_index": (C.c_ulonglong, [C.c_ulonglong, C.c_uint, C.c_uint, _i]),
     "ivosw_replay_draw_gather": (_i, [_p] * 8 + [_i, _i, _i] + [_p] * 6 + [_p]),

@@ -535,6 +535,7 @@ struct LstmBwd {
     const int64_t* action;  // [Nk]
     float* dG;           // [2,Nk,T,512] dL/d(gate pre-activation)
     int N, T;            // N = Nk
+    unsigned long long* ts;   // phase probe (ivosw_lstm_probe): stamps of the step 3 below the row's first, per workgroup, or nullptr
 };
 
 template <int R>
@@ -669,29 +670,37 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(LstmBwd p) {
         const int t = dn[r] ? p.T - 1 - sc : sc;
         return ((size_t)dn[r] * p.N + nn[r]) * p.T + t;
     };
-    float dh_rec[R], dc[R], g_cur[R], c_cur[R], c_prv[R];
+    // The kept activations of a step (its gate, its cell state, the cell state before it) are requested TWO steps ahead into
+    // a ring of three register sets with fixed roles — the loop is unrolled by three, so nothing is copied: a rotating copy
+    // (g_cur = g_nx) reads the load's destination, i.e. waits for a load that was issued at the top of the same step.
+    struct Kept { float g, c, cp; };
+    Kept ring[3][R];
+    auto fetch = [&](int s, Kept (&dst)[R]) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        dh_rec[r] = 0.f; dc[r] = 0.f;
-        g_cur[r] = p.gates[rt_of(r, smax) * 512 + q * HD + k];
-        c_cur[r] = p.cs[rt_of(r, smax) * HD + k];
-        c_prv[r] = p.cs[rt_of(r, smax - 1) * HD + k];
-    }
-    for (int s = smax; s >= 0; --s) {
-        const int buf = s & 1;
-        float g_nx[R], c_nx[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {                          // step s-1's gate and step s-2's cell state: in flight under this step
-            g_nx[r] = p.gates[rt_of(r, s - 1) * 512 + q * HD + k];
-            c_nx[r] = p.cs[rt_of(r, s - 2) * HD + k];
+        for (int r = 0; r < R; ++r) {
+            dst[r].g = p.gates[rt_of(r, s) * 512 + q * HD + k];
+            dst[r].c = p.cs[rt_of(r, s) * HD + k];
+            dst[r].cp = p.cs[rt_of(r, s - 1) * HD + k];
         }
+    };
+    float dh_rec[R], dc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { dh_rec[r] = 0.f; dc[r] = 0.f; }
+    fetch(smax, ring[0]);
+    fetch(smax - 1, ring[1]);
+    if (p.ts && tid == 0) p.ts[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime() + (unsigned long long)(w[0] == 1.2345e33f);
+    auto step = [&](int s, Kept (&cur)[R], Kept (&ahead)[R]) {
+        const int buf = s & 1;
+        const bool probe = p.ts && tid == 0 && s == smax - 3;
+        if (probe) p.ts[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime();
+        fetch(s - 2, ahead);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool act = ok[r] && s <= s0[r];
-            const float gq = g_cur[r];
+            const float gq = cur[r].g;
             const float gi = QuadDpp::mov<0x00>(gq), gf = QuadDpp::mov<0x55>(gq), gg = QuadDpp::mov<0xAA>(gq), go = QuadDpp::mov<0xFF>(gq);
-            const float cc = c_cur[r];
-            const float cprev = (s > 0) ? c_prv[r] : 0.f;
+            const float cc = cur[r].c;
+            const float cprev = (s > 0) ? cur[r].cp : 0.f;
             float dh = dh_rec[r];
             if (s == s0[r]) dh += p.dhc[(size_t)nn[r] * 256 + dn[r] * HD + k];
             const float tc = fast_tanh(cc);
@@ -708,7 +717,9 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(LstmBwd p) {
             }
             dp_s[buf][r][q * GQ + k] = mine;
         }
+        if (probe) p.ts[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
         __syncthreads();                                       // gate gradients of step s complete; buffer buf^1 (step s+1) is free
+        if (probe) p.ts[(size_t)blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
         if (s > 0) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -729,9 +740,14 @@ __global__ __launch_bounds__(512) void lstm_bwd_quad_kernel(LstmBwd p) {
                 dh_rec[r] = a;
             }
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) { g_cur[r] = g_nx[r]; c_cur[r] = c_prv[r]; c_prv[r] = c_nx[r]; }
+        if (probe) p.ts[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime() + (unsigned long long)(dh_rec[0] == 1.2345e33f);
+    };
+    for (int s = smax; s >= 0; s -= 3) {
+        step(s, ring[0], ring[2]);
+        if (s - 1 >= 0) step(s - 1, ring[1], ring[0]);
+        if (s - 2 >= 0) step(s - 2, ring[2], ring[1]);
     }
+    if (p.ts && tid == 0) { p.ts[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime(); p.ts[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)(smax + 1); }
 }
 
 // ---------------------------------------------------------------- forward driver
@@ -783,6 +799,7 @@ struct FwdPass {
     int N, N0;
     const FwdBufs* b;
 };
+static unsigned long long* g_lstm_probe_bwd = nullptr;
 static unsigned long long* g_lstm_probe = nullptr;     // set by ivosw_lstm_probe (tuning aid; never in a product call path)
 static LstmFwd lstm_fwd_args(const FwdPass& f, int T) {
     LstmFwd lf{};
@@ -1127,7 +1144,7 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     // ---- BPTT through the shared cell
     LstmBwd lb{};
     lb.whh = policy + O_WHH; lb.gates = w.pol.gates; lb.cs = w.pol.cs; lb.dhc = w.dhc; lb.action = action; lb.dG = w.dG;
-    lb.N = B; lb.T = T;
+    lb.N = B; lb.T = T; lb.ts = g_lstm_probe_bwd;
     {
         const int R = rows_per_wg(2 * B);
         const int nwg = (2 * B + R - 1) / R;
@@ -1278,7 +1295,8 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
 
 /* Tuning probe: subsequent fused forwards stamp s_memtime at four points of recurrence step T/2 per workgroup into ts
  * ([workgroups, 8] uint64 on the device: 0-3 the step's four points, 4 kernel entry, 5 weights in registers, 6 last step done; NULL switches the probe off).  tools/lstm_probe.py. */
-extern "C" int ivosw_lstm_probe(unsigned long long* ts) {
+extern "C" int ivosw_lstm_probe(unsigned long long* ts, unsigned long long* ts_bwd) {
     g_lstm_probe = ts;
+    g_lstm_probe_bwd = ts_bwd;          // BPTT kernel: 0 step start, 1 gate gradients written, 2 barrier passed, 3 matvec done, 4 / 5 loop start / end, 6 steps
     return IVOSW_OK;
 }
