@@ -180,7 +180,9 @@ def bench_assess(args, rank, world, dev, dist):
     assert torch.isfinite(out["s"]).all()
     scores = out["s"].clone()
     fps = world * args.batch * args.steps / dt
-    assert spans.value == args.steps * -(-args.batch // net_chunk(args)), (spans.value, args.steps)     # one span per ROI chunk
+    split = bool(lib.ivosw_assess_split(L.BF16 if args.precision == "bf16" else L.F32, args.batch, args.chunk or 0))
+    # one span per ROI chunk; with the two-stream split of the batch the two halves' spans form one group per forward pass
+    assert spans.value == (args.steps if split else args.steps * -(-args.batch // net_chunk(args))), (spans.value, args.steps)
     conv_ms = tot.value / args.steps
     launches = cnt.value // args.steps
     # sustained: the same measurement over >= 1 s, whatever K was
@@ -194,9 +196,11 @@ def bench_assess(args, rank, world, dev, dist):
     else:
         sus = {"value": round(fps, 1), "steps": args.steps, "seconds": round(dt, 3)}
     if args.layer_report and rank == 0:
+        lib.ivosw_tune_set(b"STREAMS2", 0)                  # per-launch events: one stream, or the halves' kernels time each other
         lib.ivosw_profile_start()
         for _ in range(3):
             step()
+        lib.ivosw_tune_set(b"STREAMS2", 1)
         buf = ctypes.create_string_buffer(1 << 16)
         lib.ivosw_profile_report(buf, len(buf))
         t2, c2 = ctypes.c_double(0), ctypes.c_int(0)
@@ -222,7 +226,9 @@ def bench_assess(args, rank, world, dev, dist):
             "hbm_GBps_of_family": hbm_gbps, "hbm_peak_GBps": 8000.0,
             "launches_per_step": launches, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
             "flops_per_launch": flops_step / max(launches, 1), "kernel_ms_per_step": round(conv_ms, 3),
-            "timing": "one HIP-event pair per forward pass around the tower's launches, inside the timed region (family time includes its own launch gaps)"}
+            "streams": 2 if split else 1,
+            "timing": "one HIP-event pair per forward pass around the tower's launches, inside the timed region (family time includes its own launch gaps)"
+                      + ("; the batch runs as two halves on two streams: family time = latest end - earliest start of the halves' tower spans" if split else "")}
     extra = {"sustained": sus}
     if rank == 0:
         pick = [0, 37, 74, 111, 148, 185, 222, args.batch - 1] if args.batch >= 256 else list(range(min(8, args.batch)))

@@ -39,6 +39,7 @@ SIGNATURES = {
     "ivosw_assess_packed_bytes": (_sz, [_i]),
     "ivosw_assess_pack": (_i, [_p, _i, C.POINTER(_p), _i, _p]),
     "ivosw_assess_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ivosw_assess_split": (_i, [_i, _i, _i]),
     "ivosw_assess_forward": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _sz, _i, _i, _p, _p]),
     "ivosw_assess_forward_objects": (_i, [_p, _i, _p, _i, _p, C.c_long, C.c_long, _i, _i, _i, _p, _p, _sz, _i, _p]),
     "ivosw_quality_state": (_i, [_p, _i, _i, _p, _p, _p, _p]),

@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <mutex>
+
 #include "conv.h"
 #include "front.h"
 
@@ -197,13 +199,33 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
     return IVOSW_OK;
 }
 
-extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk) {
-    if ((dtype != IVOSW_F32 && dtype != IVOSW_BF16) || B <= 0 || H <= 0 || W <= 0) return 0;
+static size_t ws_single(int dtype, int B, int chunk) {
     if (chunk <= 0) chunk = default_chunk(dtype);
     if (chunk > B) chunk = B;
     Arena ar(nullptr);
     return carve(ar, dtype, B, chunk, nullptr) + 256;
 }
+// Two-stream split (tunable STREAMS2, default on): a default-chunk bf16 batch of >= STREAMS2_MIN (128) units runs as two
+// independent halves, the second on the library's side stream — the fabric-bound phases of one half's kernels meet the
+// MFMA-bound phases of the other's (2 x 128 frames: 63.2 k -> 65.8 k frames/s on one box, tools/two_stream_probe.py; four
+// quarters are slower).  Per-frame results do not depend on the batch a frame travels in (tests: chunk schedules, batch
+// permutations, B = 256 against B = 8 / 64), so the split is invisible in the scores.  Each half gets its own workspace.
+static bool split_wanted(int dtype, int B, int chunk, int tap_stage) {
+    return dtype == IVOSW_BF16 && chunk <= 0 && tap_stage == 0 && tune_get("STREAMS2", 1) && B >= std::max(2, tune_get("STREAMS2_MIN", 128));
+}
+static int split_first_half(int B) { return (B / 2 + 7) / 8 * 8; }
+static size_t ws_split(int dtype, int B) {
+    const int B0 = split_first_half(B);
+    return align_up(ws_single(dtype, B0, 0), 256) + ws_single(dtype, B - B0, 0);
+}
+
+extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk) {
+    if ((dtype != IVOSW_F32 && dtype != IVOSW_BF16) || B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t one = ws_single(dtype, B, chunk);
+    return split_wanted(dtype, B, chunk, 0) ? std::max(one, ws_split(dtype, B)) : one;
+}
+
+extern "C" int ivosw_assess_split(int dtype, int B, int chunk) { return split_wanted(dtype, B, chunk, 0) ? 1 : 0; }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
     return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
@@ -231,6 +253,42 @@ extern "C" int ivosw_assess_forward_objects(const void* packed, int dtype, const
                                W, scores, ws, ws_bytes, chunk, 0, nullptr, stream);
 }
 
+// units [u0, u0 + B) of the batch on stream st with their own workspace; `slot` = which of the (up to two) concurrent profiler spans
+static void assess_forward_range(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int u0, int B,
+                                 int H, int W, float* scores, void* ws, int chunk, int tap_stage, void* tap_out, int slot, hipStream_t st);
+
+// One helper stream + two events per device for the two-stream split (created on first use, all-or-nothing; the call holds
+// the device's mutex while it enqueues so two host threads cannot interleave their fork / join pairs).
+namespace {
+struct Side2 {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {};
+    bool tried = false;
+};
+Side2* side2_for_current_device() {
+    static Side2 sides[64];
+    static std::mutex init_mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    Side2& s = sides[dev];
+    std::lock_guard<std::mutex> lk(init_mu);
+    if (!s.tried) {
+        s.tried = true;
+        bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+        int made = 0;
+        for (; ok && made < 2; ++made) ok = hipEventCreateWithFlags(&s.ev[made], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (int i = 0; i < made; ++i) if (s.ev[i]) (void)hipEventDestroy(s.ev[i]);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            s.stream = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    return s.stream ? &s : nullptr;
+}
+}  // namespace
+
 static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,
                                float* scores, void* ws, size_t ws_bytes, int chunk, int tap_stage, void* tap_out,
                                ivosw_stream_t stream) {
@@ -240,14 +298,44 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
     IVOSW_REQUIRE(tap_stage >= 0 && tap_stage <= 8, "tap_stage out of range");
     IVOSW_REQUIRE(tap_stage == 0 || tap_out, "tap_out is null");
+    const bool want_split = split_wanted(dtype, B, chunk, tap_stage);
     if (chunk <= 0) chunk = default_chunk(dtype);
     if (chunk > B) chunk = B;
     IVOSW_REQUIRE(tap_stage == 0 || B <= chunk, "taps need B <= chunk");
-    if (ws_bytes < ivosw_assess_ws_bytes(dtype, B, H, W, chunk)) {
+    if (ws_bytes < ws_single(dtype, B, chunk)) {
         set_error("ivosw_assess_forward: workspace %zu < %zu", ws_bytes, ivosw_assess_ws_bytes(dtype, B, H, W, chunk));  // B = units
         return IVOSW_ERR_WS;
     }
     hipStream_t st = as_stream(stream);
+    Side2* sd = (want_split && ws_bytes >= ws_split(dtype, B)) ? side2_for_current_device() : nullptr;
+    if (sd) {
+        std::lock_guard<std::mutex> lk(sd->mu);
+        const int B0 = split_first_half(B), B1 = B - B0;
+        char* ws1 = static_cast<char*>(ws) + align_up(ws_single(dtype, B0, 0), 256);
+        bool ok = hipEventRecord(sd->ev[0], st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->ev[0], 0) == hipSuccess;
+        if (ok) {
+            span_group_begin();
+            assess_forward_range(packed, dtype, tf, tp, sm, 0, B0, H, W, scores, ws, std::min(default_chunk(dtype), B0), 0, nullptr, 0, st);
+            assess_forward_range(packed, dtype, tf, tp, sm, B0, B1, H, W, scores + B0, ws1, std::min(default_chunk(dtype), B1), 0, nullptr, 1, sd->stream);
+            span_group_end();
+            ok = hipEventRecord(sd->ev[1], sd->stream) == hipSuccess && hipStreamWaitEvent(st, sd->ev[1], 0) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                set_error("ivosw_assess_forward: the join of the two streams failed");
+                return IVOSW_ERR_LAUNCH;
+            }
+            IVOSW_CHECK_LAUNCH();
+            return IVOSW_OK;
+        }
+        (void)hipGetLastError();        // the fork failed before anything was enqueued on the side stream: run on one stream
+    }
+    assess_forward_range(packed, dtype, tf, tp, sm, 0, B, H, W, scores, ws, chunk, tap_stage, tap_out, 0, st);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+static void assess_forward_range(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int u0, int B,
+                                 int H, int W, float* scores, void* ws, int chunk, int tap_stage, void* tap_out, int slot, hipStream_t st) {
     const Plan& P = plan_for(dtype);
     const size_t es = (dtype == IVOSW_BF16) ? 2 : 4;
     const char* base = static_cast<const char*>(packed);
@@ -259,7 +347,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
     };
 
     // K1/K2: mask -> (y,x,h,w) for the whole batch, on device
-    launch_mask_bbox(tp, 0, B, H, W, sm, bf.yxhw, bf.box, st);
+    launch_mask_bbox(tp, u0, B, H, W, sm, bf.yxhw, bf.box, st);
     // Encoder.mean/std come from the checkpoint: the sampler reads them from the packed arena
     RoiNorm nrm{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, reinterpret_cast<const float*>(base + P.norm_off)};
 
@@ -393,11 +481,11 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                 for (int f0 = f1; f0 < f1 + n1; f0 += cs[0]) {
                     const int nb = std::min(cs[0], f1 + n1 - f0);
                     // K3: ROI crop-resize + normalise -> NHWC4
-                    span_close(st);
-                    launch_roi_sample(tf, tp, bf.yxhw + (size_t)f0 * 4, f0, nb, H, W, dtype, sm, nrm, bf.roi, st);
+                    span_close(st, slot);
+                    launch_roi_sample(tf, tp, bf.yxhw + (size_t)f0 * 4, u0 + f0, nb, H, W, dtype, sm, nrm, bf.roi, st);
                     tap(1, bf.roi, nb * E_ROI * es);
                     // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool (bf16: one fused kernel unless the stem tap is wanted)
-                    span_open(st);
+                    span_open(st, slot);
                     if (dtype == IVOSW_BF16 && tap_stage != 2 && tune_get("FUSE_STEM", 1)) {
                         launch_stem_pool(bf.roi, base + P.stem_w_off, reinterpret_cast<const float*>(base + P.stem_b_off), nb, bf.pa, st);
                     } else {
@@ -425,11 +513,9 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
         run_stage(3, bf.in[2], n3, bf.pa, 0);  // c0*8 frames x 131k elements == c0 * E_BIG: fits a ping-pong buffer
         tap(7, bf.pa, n3 * E_OUT[3] * es);
         // K6: 8x8 average pool + fc1
-        span_close(st);
+        span_close(st, slot);
         launch_pool_fc(bf.pa, n3, dtype, reinterpret_cast<const float*>(base + P.fcw_off),
                        reinterpret_cast<const float*>(base + P.fcb_off), scores + f3, tap_stage == 8 ? bf.pooled : nullptr, st);
         tap(8, bf.pooled, (size_t)n3 * 2048 * sizeof(float));
     }
-    IVOSW_CHECK_LAUNCH();
-    return IVOSW_OK;
 }

@@ -40,8 +40,10 @@ struct BneckArgs {
 };
 void* prof_begin(const ConvArgs& a, int es, hipStream_t st);   // measurement hook (ivosw_profile_*), see conv.hip
 void prof_end(void* tok, hipStream_t st);
-void span_open(hipStream_t st);    // span mode: start / end of an uninterrupted run of tower launches (assess.hip)
-void span_close(hipStream_t st);
+void span_open(hipStream_t st, int slot = 0);    // span mode: start / end of an uninterrupted run of tower launches (assess.hip)
+void span_close(hipStream_t st, int slot = 0);
+void span_group_begin();                         // the spans opened until span_group_end() belong to ONE forward pass (two streams)
+void span_group_end();
 bool bneck_fusable(const BneckArgs& a);
 void launch_bneck(const BneckArgs& a, hipStream_t st);
 

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
             const int f = hr / HP, rem = hr - f * HP;
             const int hy = rem / HW2, hx = rem - hy * HW2;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = g < NG && hr < HRT && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            const bool ok = g < NG && hr < HRT && y >= 0 && y < p.H && x >= 0 && x < p.W && b0 + f < p.B;   // (frames past the batch in the last 4-frame tile read zeros)
             abase[i] = ok ? X + (((long)(b0 + f) * p.H + y) * p.W + x) * p.Cin + (cpos ^ ((hr >> 1) & 7)) * CE : zeros;
             okmask |= ok ? (1u << i) : 0u;
         }
@@ -805,6 +805,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
         const int row = item / CPR, cg = item - row * CPR;
         const int f = row / (TH * TW), rem = row - f * (TH * TW);
         const int y = rem / TW, x = rem - y * TW;
+        if (F > 1 && b0 + f >= p.B) continue;                  // partial last tile (B % F != 0)
         const long o = ((((long)(b0 + f) * p.H + y0 + y) * p.W + x0 + x)) * p.Cout + n0 + cg * 8;
         const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
         const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
@@ -828,7 +829,9 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
 // shapes covered by conv3x3_patch_kernel
 static bool patch3x3_ok(const ConvArgs& a) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.res || a.H != a.W || a.Cin % 64 || a.Cout % 128) return false;
-    return (a.H == 32 || a.H == 16) || (a.H == 8 && a.B % 4 == 0);
+    // the rule looks at the layer shape only, never at the batch (a frame's result must not depend on the batch it travels in:
+    // B % 4 != 0 at H == 8 used to fall back to the per-tap kernel for the WHOLE launch, i.e. another summation order)
+    return a.H == 32 || a.H == 16 || a.H == 8;
 }
 
 template <typename T, bool STEM>
@@ -848,7 +851,7 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
             static const int use_ws = getenv("IVOSW_TUNE_WS") ? atoi(getenv("IVOSW_TUNE_WS")) : 1;
             if constexpr (sizeof(T) == 2) {
                 if (patch3x3_ok(a) && tune_get("PATCH3", 1)) {
-                    const int g3 = (M / 256) * (a.Cout / 128);
+                    const int g3 = ((M + 255) / 256) * (a.Cout / 128);      // H == 8: four frames per tile, the last one may be partial
                     if (a.H == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 8>), dim3(g3), dim3(1024), 0, st, a);
                     else hipLaunchKernelGGL((conv3x3_patch_kernel<1, 16>), dim3(g3), dim3(1024), 0, st, a);
                     return;
@@ -883,35 +886,45 @@ struct ConvProfiler {
     // span mode (ivosw_profile_span_*): ONE event pair around each uninterrupted run of tower launches (stem .. last res5
     // kernel of a pass), so the family time contains its own launch gaps but no per-launch event overhead, and
     // family time <= wall time of the step holds by construction
-    bool span_on = false, span_is_open = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> sev;
+    // With the two-stream split of a batch (assess.hip) two spans run concurrently, one per stream: spans of one forward
+    // pass form a GROUP whose time is latest end - earliest start (the wall interval during which tower kernels ran).
+    struct SpanRec { hipEvent_t a, b; int group; };
+    bool span_on = false, span_open_[2] = {false, false};
+    size_t span_idx[2] = {0, 0};
+    std::vector<SpanRec> sev;
     size_t sused = 0;
+    int group_next = 0, group_forced = -1;
     long span_launches = 0;
 };
 static ConvProfiler g_prof;
 
-void span_open(hipStream_t st) {
-    if (!g_prof.span_on || g_prof.span_is_open) return;
+void span_group_begin() {
+    if (g_prof.span_on) g_prof.group_forced = g_prof.group_next++;
+}
+void span_group_end() { g_prof.group_forced = -1; }
+void span_open(hipStream_t st, int slot) {
+    if (!g_prof.span_on || g_prof.span_open_[slot]) return;
     if (g_prof.sused == g_prof.sev.size()) {
         hipEvent_t x, y;
         (void)hipEventCreate(&x);
         (void)hipEventCreate(&y);
-        g_prof.sev.emplace_back(x, y);
+        g_prof.sev.push_back({x, y, 0});
     }
-    (void)hipEventRecord(g_prof.sev[g_prof.sused].first, st);
-    g_prof.span_is_open = true;
+    g_prof.sev[g_prof.sused].group = g_prof.group_forced >= 0 ? g_prof.group_forced : g_prof.group_next++;
+    (void)hipEventRecord(g_prof.sev[g_prof.sused].a, st);
+    g_prof.span_idx[slot] = g_prof.sused++;
+    g_prof.span_open_[slot] = true;
 }
-void span_close(hipStream_t st) {
-    if (!g_prof.span_on || !g_prof.span_is_open) return;
-    (void)hipEventRecord(g_prof.sev[g_prof.sused].second, st);
-    ++g_prof.sused;
-    g_prof.span_is_open = false;
+void span_close(hipStream_t st, int slot) {
+    if (!g_prof.span_on || !g_prof.span_open_[slot]) return;
+    (void)hipEventRecord(g_prof.sev[g_prof.span_idx[slot]].b, st);
+    g_prof.span_open_[slot] = false;
 }
 
 // begin/end of one profiled launch: `a` describes the layer for the report (KH == 0 marks a fused bottleneck:
 // Cin -> Cout/4 -> Cout/4 (3x3) -> Cout + residual)
 void* prof_begin(const ConvArgs& a, int es, hipStream_t st) {
-    if (g_prof.span_on && g_prof.span_is_open) ++g_prof.span_launches;
+    if (g_prof.span_on && (g_prof.span_open_[0] || g_prof.span_open_[1])) ++g_prof.span_launches;
     if (!g_prof.on) return nullptr;
     if (g_prof.used == g_prof.ev.size()) {
         hipEvent_t x, y;
@@ -1134,10 +1147,13 @@ void launch_pool_fc(const void* x, int B, int dtype, const float* fcw, const flo
 }  // namespace ivosw
 
 extern "C" int ivosw_profile_span_start(void) {
-    ivosw::g_prof.span_on = true;
-    ivosw::g_prof.span_is_open = false;
-    ivosw::g_prof.sused = 0;
-    ivosw::g_prof.span_launches = 0;
+    using namespace ivosw;
+    g_prof.span_on = true;
+    g_prof.span_open_[0] = g_prof.span_open_[1] = false;
+    g_prof.sused = 0;
+    g_prof.group_next = 0;
+    g_prof.group_forced = -1;
+    g_prof.span_launches = 0;
     return IVOSW_OK;
 }
 
@@ -1145,16 +1161,26 @@ extern "C" int ivosw_profile_span_stop(double* total_ms, int* spans, int* launch
     using namespace ivosw;
     IVOSW_REQUIRE(total_ms && spans && launches, "null pointer");
     double tot = 0.0;
-    for (size_t i = 0; i < g_prof.sused; ++i) {
-        (void)hipEventSynchronize(g_prof.sev[i].second);
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_prof.sev[i].first, g_prof.sev[i].second) == hipSuccess) tot += ms;
+    for (size_t i = 0; i < g_prof.sused; ++i) (void)hipEventSynchronize(g_prof.sev[i].b);
+    for (size_t i = 0; i < g_prof.sused;) {      // the spans of a group are consecutive
+        size_t j = i;
+        while (j < g_prof.sused && g_prof.sev[j].group == g_prof.sev[i].group) ++j;
+        // latest end - earliest start of the group's spans = the largest (end_y - start_x)
+        float best = 0.f;
+        for (size_t x = i; x < j; ++x)
+            for (size_t y = i; y < j; ++y) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, g_prof.sev[x].a, g_prof.sev[y].b) == hipSuccess) best = std::max(best, ms);
+            }
+        tot += best;
+        i = j;
     }
+    (void)hipGetLastError();
     *total_ms = tot;
-    *spans = (int)g_prof.sused;
+    *spans = g_prof.group_next;
     *launches = (int)g_prof.span_launches;
     g_prof.span_on = false;
-    g_prof.span_is_open = false;
+    g_prof.span_open_[0] = g_prof.span_open_[1] = false;
     g_prof.sused = 0;
     return IVOSW_OK;
 }

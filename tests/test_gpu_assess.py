@@ -395,3 +395,53 @@ def test_conv1_forwarding_through_res2_is_bit_identical(dev, net16):
             lib.ivosw_tune_set(b"FWD2", 1)
         for a, b, nm in zip(got[1], got[0], ("res2", "res3", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
+
+
+def test_two_stream_split_is_invisible_in_the_scores(dev, net16):
+    """bf16, default chunk, B >= 128: ivosw_assess_forward runs the batch as two halves on two streams (tunable STREAMS2=1, default;
+    the second half on the library's side stream with its own workspace).  A frame's score does not depend on the batch it travels
+    in, so the scores must equal the one-stream run bit for bit — for an even split (256), an uneven one (136 -> 72 + 64) and
+    the multi-object entry (3 objects x 50 frames = 150 units, one copy of the frames); back-to-back calls on the caller's
+    stream see each other's results in order (the join)."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    assert lib.ivosw_assess_split(L.BF16, 256, 0) == 1 and lib.ivosw_assess_split(L.BF16, 64, 0) == 0
+    assert lib.ivosw_assess_split(L.F32, 256, 0) == 0 and lib.ivosw_assess_split(L.BF16, 256, 64) == 0
+    _, _, tf8, tp8 = inputs(dev, 8, True)
+    for B in (256, 136):
+        ttf = tf8.repeat((B + 7) // 8, 1, 1, 1)[:B].contiguous()
+        ttp = tp8.repeat((B + 7) // 8, 1, 1)[:B].contiguous()
+        ttp = torch.roll(ttp, shifts=3, dims=0).contiguous()          # frame i with the mask of frame i - 3: B distinct pairs per 8
+        got = {}
+        try:
+            for mode in (1, 0, 1):
+                lib.ivosw_tune_set(b"STREAMS2", mode)
+                a = net16(ttf, ttp).clone()
+                b = net16(ttf.flip(0).contiguous(), ttp.flip(0).contiguous()).clone()      # immediately after, same stream
+                got.setdefault(mode, []).append((a, b))
+        finally:
+            lib.ivosw_tune_set(b"STREAMS2", 1)
+        for a, b in got[1]:
+            assert torch.equal(a, got[0][0][0]) and torch.equal(b, got[0][0][1]), B
+            assert torch.equal(a, b.flip(0)), B
+    # ... and of the batch SIZE, multiples of 4 or not (res5's patch-resident 3x3 packs four 8x8 frames per tile: with B % 4 != 0
+    # the whole launch used to fall back to the per-tap kernel, another summation order): every frame of a 150- / 67-frame
+    # batch scores what it scores in a launch of its 8 neighbours
+    for B in (150, 67):
+        ttf = tf8.repeat((B + 7) // 8, 1, 1, 1)[:B].contiguous()
+        ttp = torch.roll(tp8.repeat((B + 7) // 8, 1, 1)[:B], shifts=3, dims=0).contiguous()
+        whole = net16(ttf, ttp).clone().reshape(-1)
+        parts = torch.cat([net16(ttf[i:i + 8].contiguous(), ttp[i:i + 8].contiguous()).reshape(-1) for i in range(0, B, 8)])
+        assert torch.equal(whole, parts), B
+    # multi-object entry: units = obj * n_frames + frame over ONE copy of the frames
+    n, O = 50, 3
+    ttf = tf8.repeat(7, 1, 1, 1)[:n].contiguous()
+    all_p = torch.stack([torch.roll(tp8.repeat(7, 1, 1)[:n], shifts=o, dims=0) for o in range(O + 1)], 1).contiguous()   # [n, O+1, H, W]
+    try:
+        lib.ivosw_tune_set(b"STREAMS2", 1)
+        s1 = net16.forward_objects(ttf, all_p, O).clone()
+        lib.ivosw_tune_set(b"STREAMS2", 0)
+        s0 = net16.forward_objects(ttf, all_p, O).clone()
+    finally:
+        lib.ivosw_tune_set(b"STREAMS2", 1)
+    assert torch.equal(s1, s0)
