@@ -287,15 +287,28 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     from ivos_w_amd.models.agent import CapturedDqnStep
     agent, replay, gen = build_dqn(args, rank, dev)
     B = args.minibatch
-    fused = world == 1
+    from ivos_w_amd import parallel
+    dp = world > 1 or args.dqn_dp_emulate          # the data-parallel step structure (gradients -> collective -> clamp + Adam)
+    fused = not dp
+    seed = 2019 + 7919 * rank
+    lean = None
     if args.dqn_eager:
         cap = None
+    elif dp and args.dqn_dp == "eager":
+        # N > 1, default: plain launches (10 per step + the collective) from preallocated buffers.  A captured graph buys nothing
+        # here — the host has a collective to enqueue every step anyway — and costs the 8.7 us bubble around each graph launch
+        cap = None
+        lean = dict(draw=replay.draw_state(seed), bufs=None)
     else:
-        cap = CapturedDqnStep(agent, replay, B, fused=fused, draw_seed=None if os.environ.get("IVOSW_BENCH_HOST_DRAW") else 2019 + 7919 * rank)
+        cap = CapturedDqnStep(agent, replay, B, fused=fused, draw_seed=None if os.environ.get("IVOSW_BENCH_HOST_DRAW") else seed)
     nrep = len(replay)
+    p2p = parallel.p2p_for(agent.policy_net.flat_grad) if world > 1 else None      # collective decision (self-test), outside the timed region
 
     def step():
-        if cap is None:
+        if lean is not None:
+            lean["bufs"] = replay.sample_drawn(B, lean["draw"], out=lean["bufs"])
+            agent.loss_and_grads(lean["bufs"])
+        elif cap is None:
             idx = torch.randint(0, nrep, (B,), device=dev, generator=gen)
             agent.loss_and_grads(replay.sample(idx))
         else:
@@ -303,8 +316,7 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
                 torch.randint(0, nrep, (B,), device=dev, generator=gen, out=cap.idx)
             cap.launch()
         if world > 1:
-            allreduce_grads(dist, agent.policy_net.flat_grad)
-            agent.optimizer.grad_scale = 1.0 / world
+            agent.optimizer.grad_scale = parallel.allreduce_grads(agent.policy_net.flat_grad)     # one-shot xGMI P2P, else RCCL
         if cap is None or not fused:
             agent.optimizer.step()
         if np.random.random() < agent.update_rate:
@@ -334,7 +346,13 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     assert torch.isfinite(agent.policy_net.flat).all() and agent.optimizer.state["step"] >= steps + warmup
     sps = world * steps / dt
     per_gpu_tflops = DQN_GFLOP_PER_STEP * 1e9 * (sps / world) / 1e12
+    if p2p is not None:
+        torch.cuda.synchronize(dev)
+        assert p2p.error() == 0, "the peer-to-peer all-reduce timed out waiting for a rank"
     info = {"us_per_step": round(dt / steps * 1e6, 1), "graph": cap is not None,
+            "step_structure": "data-parallel: gradients -> collective -> clamp + Adam" + (" (emulated at N = 1, no collective)" if world == 1 else "") if dp else "single GPU: fused step",
+            "collective_path": (("one-shot xGMI peer-to-peer all-reduce (ivosw_p2p_allreduce, self-tested against the RCCL result at start-up)" if p2p is not None
+                                 else "RCCL all-reduce" if BACKEND[0] == "nccl" else "gloo all-reduce staged through host memory") if world > 1 else None),
             "kernel_nodes_in_graph": cap.kernel_nodes if cap is not None else None,
             "host_launches_per_step": (round(launches_per_step, 3) if loop is not None else (1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
             "steps_per_graph_launch": args.dqn_block if loop is not None else (1 if cap is not None else None),
@@ -534,6 +552,8 @@ def main():
     ap.add_argument("--minibatch", type=int, default=128)
     ap.add_argument("--replay", type=int, default=50000)
     ap.add_argument("--dqn-steps", type=int, default=2000)
+    ap.add_argument("--dqn-dp", choices=["eager", "graph"], default="eager", help="N > 1: plain launches (default) or a captured graph for the gradient part of the step")
+    ap.add_argument("--dqn-dp-emulate", action="store_true", help="N = 1: run the data-parallel step structure (no collective) to time it")
     ap.add_argument("--dqn-block", type=int, default=8, help="N = 1: training steps per hipGraphLaunch when no target-sync coin of the block fires (1 = one graph launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-report", default="", help="write a per-conv-layer timing table (HIP events) to this file")
@@ -560,7 +580,7 @@ def main():
                      "dqn": dict({"metric": "dqn_agent_steps_per_sec", "value": round(dqn_sps, 1), "unit": "minibatch-steps/s (all ranks)",
                                   "transitions_per_sec": round(dqn_sps * args.minibatch, 1), "minibatch_per_gpu": args.minibatch,
                                   "replay": args.replay, "T": 25, "steps": args.dqn_steps,
-                                  "dtype": "f32", "collective": (f"{'rccl' if args.backend == 'nccl' else 'gloo (host-staged)'} all_reduce(724KB)") if world > 1 else None}, **dqn_info)})
+                                  "dtype": "f32", "collective": (dqn_info.get("collective_path") + " (724 KB)") if world > 1 else None}, **dqn_info)})
         line.update(extra)
     else:
         sps, dt, info = bench_dqn(args, rank, world, dev, dist, args.steps, args.warmup)

@@ -82,6 +82,26 @@ int ivosw_clamp_adam_dev(float* params, const float* grads, float* exp_avg, floa
 /* Replaces target_net.load_state_dict(policy_net.state_dict()) (models/agent.py:163-165).        */
 int ivosw_copy_f32(float* dst, const float* src, size_t n, ivosw_stream_t stream);
 
+/* ------------------------------------------------------------------ one-shot P2P all-reduce --- */
+/* The data-parallel DQN step's gradient all-reduce (Agent.update_agent under torch.distributed; the reference is single
+ * GPU) over xGMI peer-to-peer writes instead of a ring: every rank pushes its n floats into its slot of every peer's arena and
+ * raises a flag there (7 links in parallel, one hop), then sums the `world` slots it received in rank order (bit-identical
+ * on all ranks).  The arena is FINE-GRAINED device memory (coherent inside kernels across GPUs) — the one device allocation the
+ * library makes itself: ivosw_p2p_alloc (returns the pointer and an IPC handle of ivosw_p2p_handle_bytes() bytes to send to
+ * the peers) / ivosw_p2p_free; peers map it with ivosw_p2p_open / unmap with ivosw_p2p_close.  ivosw_p2p_allreduce:
+ * arenas = HOST array of `world` device pointers (own arena at [rank]); epoch = 1, 2, 3, ... identical on every rank, one per
+ * call; out may alias grads (16-byte aligned); a peer that does not arrive within timeout_ms sets the arena's error word
+ * (ivosw_p2p_error) instead of hanging the GPU.  Two kernels per call, no host synchronisation.                           */
+size_t ivosw_p2p_arena_bytes(int world, size_t n);
+size_t ivosw_p2p_handle_bytes(void);
+int ivosw_p2p_alloc(size_t bytes, void** arena, void* ipc_handle, size_t ipc_handle_bytes);
+int ivosw_p2p_open(const void* ipc_handle, void** peer_arena);
+int ivosw_p2p_close(void* peer_arena);
+int ivosw_p2p_free(void* arena);
+int ivosw_p2p_error(const void* arena, int* error);
+int ivosw_p2p_allreduce(const float* grads, float* out, int n, int rank, int world, void* const* arenas, unsigned epoch,
+                        int timeout_ms, ivosw_stream_t stream);
+
 /* ------------------------------------------------------------------ replay gather (K11) ------- */
 /* Replaces DataLoader shuffle+collate of memory_pool.csv rows (datasets/agent_dataset.py:71-115,
  * train_agent.py:177-182) for a device-resident SoA replay buffer: columns [cap,T] fp32 and [cap]

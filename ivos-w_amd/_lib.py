@@ -29,6 +29,14 @@ SIGNATURES = {
     "ivosw_adam_state_bytes": (_sz, []),
     "ivosw_clamp_adam_dev": (_i, [_p, _p, _p, _p, _i, _p, _f, _f, _f, _f, _f, _f, _f, _p]),
     "ivosw_copy_f32": (_i, [_p, _p, _sz, _p]),
+    "ivosw_p2p_arena_bytes": (_sz, [_i, _sz]),
+    "ivosw_p2p_handle_bytes": (_sz, []),
+    "ivosw_p2p_alloc": (_i, [_sz, C.POINTER(_p), _p, _sz]),
+    "ivosw_p2p_open": (_i, [_p, C.POINTER(_p)]),
+    "ivosw_p2p_close": (_i, [_p]),
+    "ivosw_p2p_free": (_i, [_p]),
+    "ivosw_p2p_error": (_i, [_p, C.POINTER(_i)]),
+    "ivosw_p2p_allreduce": (_i, [_p, _p, _i, _i, _i, C.POINTER(_p), C.c_uint, _i, _p]),
     "ivosw_replay_gather": (_i, [_p] * 8 + [_i, _i] + [_p] * 5 + [_p]),
     "ivosw_lstm_probe": (_i, [_p, _p]),
     "ivosw_replay_draw_state_bytes": (_sz, []),

@@ -104,10 +104,12 @@ def test_world2_product_path_matches_single_process_full_batch():
     assert np.array_equal(res[0][-1][2], res[0][-1][1]) == bool(torch.equal(agent.target_net.flat, agent.policy_net.flat))
 
 
-def test_bench_multi_rank_branch_under_torchrun(tmp_path):
+@pytest.mark.parametrize("variant", ["default", "graph_no_p2p"])
+def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     """bench.py's N > 1 branch exactly as the driver launches it (torch.distributed.run, one process per rank, barrier + max over
-    ranks, rank 0 prints the line) — on this one-GPU box with both ranks on cuda:0 and the gloo backend staging the collective
-    through host memory (two ranks cannot share a device under RCCL).  Frames are sharded (weak scaling), the DQN leg all-reduces
+    ranks, rank 0 prints the line) — on this one-GPU box with both ranks on cuda:0 and the gloo rendezvous (two ranks cannot
+    share a device under RCCL).  default: plain launches + the one-shot peer-to-peer all-reduce (IPC-mapped arenas of the two
+    processes); graph_no_p2p: captured gradient graph + the collective of the backend (IVOSW_P2P=0: gloo staged through host memory).  Frames are sharded (weak scaling), the DQN leg all-reduces
     its gradient arena every step."""
     import json
     import subprocess
@@ -118,9 +120,13 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path):
     port = s_.getsockname()[1]
     s_.close()
     env = dict(os.environ, IVOSW_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    extra = []
+    if variant == "graph_no_p2p":
+        env["IVOSW_P2P"] = "0"
+        extra = ["--dqn-dp", "graph"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--min-warm-s", "0",
-           "--batch", "16", "--dqn-steps", "30", "--backend", "gloo", "--no-fp32"]
+           "--batch", "16", "--dqn-steps", "30", "--backend", "gloo", "--no-fp32"] + extra
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -128,4 +134,57 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0 and d["checked"] is True
     assert d["config"]["parallelism"] == "frames sharded x2" and "cpu_baseline" not in d
-    assert d["dqn"]["value"] > 0 and "all_reduce" in d["dqn"]["collective"] and d["dqn"]["graph"] is True
+    assert d["dqn"]["value"] > 0 and "all-reduce" in d["dqn"]["collective"]
+    if variant == "default":
+        assert "peer-to-peer" in d["dqn"]["collective"] and d["dqn"]["graph"] is False
+    else:
+        assert "gloo" in d["dqn"]["collective"] and d["dqn"]["graph"] is True
+
+
+def _p2p_worker(rank, world, port, q):
+    from ivos_w_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    r, w, dev = parallel.init("gloo")
+    n = 180993
+    p2p = parallel.P2PAllReduce.create(n, dev)
+    if p2p is None:
+        q.put((rank, None))
+    else:
+        g = torch.Generator(device="cpu").manual_seed(77 + rank)
+        outs = []
+        for it in range(12):                                   # both slot parities, many re-uses, no host sync in between
+            x = torch.randn(n, generator=g).to(dev) * (1 + it)
+            p2p(x)
+            outs.append(x)
+        torch.cuda.synchronize(dev)
+        assert p2p.error() == 0
+        q.put((rank, [o.cpu().numpy() for o in outs]))
+        p2p.close()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_p2p_allreduce_two_ranks_on_one_device():
+    """The one-shot peer-to-peer all-reduce (csrc/p2p.hip) with two processes on one MI355X: IPC-mapped fine-grained arenas,
+    push + flag + reduce kernels, 12 back-to-back calls without host synchronisation.  Result = the rank-ordered fp32 sum of the
+    two inputs, bit-identical on both ranks.  (Across GPUs the same kernels write over xGMI; that part cannot run here.)"""
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0] is not None and res[1] is not None, "P2PAllReduce.create fell back (IPC mapping or self-test failed)"
+    gens = [torch.Generator(device="cpu").manual_seed(77 + r) for r in range(2)]
+    for it in range(12):
+        xs = [torch.randn(180993, generator=g).numpy() * np.float32(1 + it) for g in gens]
+        want = xs[0] + xs[1]                                   # rank order
+        np.testing.assert_array_equal(res[0][it], want)
+        np.testing.assert_array_equal(res[1][it], want)
