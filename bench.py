@@ -321,26 +321,33 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
             agent.optimizer.step()
         if np.random.random() < agent.update_rate:
             agent.sync_target()
-    loop = None
+    loop, launch_mode = None, None
     if cap is not None and fused and cap.draw is not None and args.dqn_block > 1:
         # N = 1: the same steps in blocks of `dqn_block` per hipGraphLaunch whenever no target-sync coin of the block fires
         # (GraphedDqnLoop: same coin stream, same minibatch stream, bit-identical results; an 8.7 us bubble separates two
         # graph launches).  Timed like `timed()`: warm-up, synchronize, EXACTLY `steps` steps, synchronize.
-        from ivos_w_amd.models.agent import GraphedDqnLoop
-        loop = GraphedDqnLoop(agent, replay, B, draw_seed=2019 + 7919 * rank, block=args.dqn_block)
-        cap = loop.one
+        # Launch mode (--dqn-mode): "graph" = those blocks, "plain" = ten plain launches per step from preallocated buffers (no
+        # bubble between graph launches; needs a host that keeps ahead of ~190 us of GPU work per step), "auto" (default) = the
+        # warm-up runs 2 x 128 steps through each and the timed region uses the faster one.  The modes are bit-identical.
+        from ivos_w_amd.models.agent import AutoDqnLoop
+        auto = AutoDqnLoop(agent, replay, B, draw_seed=2019 + 7919 * rank, block=args.dqn_block)
+        if args.dqn_mode != "auto":
+            auto.choice = args.dqn_mode
+        cap = auto.graphed.one
         t_w = time.perf_counter()
-        loop.run(warmup)
+        auto.run(max(warmup, 2 * auto.probe if auto.choice is None else 0))
         torch.cuda.synchronize(dev)
         while time.perf_counter() - t_w < min(args.min_warm_s, 0.5):
-            loop.run(max(1, warmup))
+            auto.run(max(1, warmup))
             torch.cuda.synchronize(dev)
-        l0 = loop.launches
+        loop = auto.graphed if auto.choice == "graph" else None
+        l0 = auto.graphed.launches
         t0 = time.perf_counter()
-        loop.run(steps)
+        auto.run(steps)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
-        launches_per_step = (loop.launches - l0) / steps
+        launches_per_step = (auto.graphed.launches - l0) / steps if auto.choice == "graph" else 10.0
+        launch_mode = {"mode": auto.choice, "requested": args.dqn_mode, "probe_us_per_step": {k: round(v, 1) for k, v in auto.probe_us.items()}}
     else:
         dt = timed(step, steps, warmup, dev, dist, min(args.min_warm_s, 0.5))
     assert torch.isfinite(agent.policy_net.flat).all() and agent.optimizer.state["step"] >= steps + warmup
@@ -349,12 +356,13 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     if p2p is not None:
         torch.cuda.synchronize(dev)
         assert p2p.error() == 0, "the peer-to-peer all-reduce timed out waiting for a rank"
-    info = {"us_per_step": round(dt / steps * 1e6, 1), "graph": cap is not None,
+    info = {"us_per_step": round(dt / steps * 1e6, 1), "graph": (cap is not None) if launch_mode is None else launch_mode["mode"] == "graph",
+            "launch_mode": launch_mode,
             "step_structure": "data-parallel: gradients -> collective -> clamp + Adam" + (" (emulated at N = 1, no collective)" if world == 1 else "") if dp else "single GPU: fused step",
             "collective_path": (("one-shot xGMI peer-to-peer all-reduce (ivosw_p2p_allreduce, self-tested against the RCCL result at start-up)" if p2p is not None
                                  else "RCCL all-reduce" if BACKEND[0] == "nccl" else "gloo all-reduce staged through host memory") if world > 1 else None),
             "kernel_nodes_in_graph": cap.kernel_nodes if cap is not None else None,
-            "host_launches_per_step": (round(launches_per_step, 3) if loop is not None else (1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
+            "host_launches_per_step": (round(launches_per_step, 3) if launch_mode is not None else (1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
             "steps_per_graph_launch": args.dqn_block if loop is not None else (1 if cap is not None else None),
             "minibatch_draw": "device (ivosw_replay_draw_gather, inside the graph)" if cap is not None and cap.draw is not None else "torch.randint",
             "roofline": {"bound": "mfma", "achieved": round(per_gpu_tflops, 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -552,6 +560,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=128)
     ap.add_argument("--replay", type=int, default=50000)
     ap.add_argument("--dqn-steps", type=int, default=2000)
+    ap.add_argument("--dqn-mode", choices=["auto", "graph", "plain"], default="auto", help="N = 1: how the training steps are launched (auto: measured in the warm-up)")
     ap.add_argument("--dqn-dp", choices=["eager", "graph"], default="eager", help="N > 1: plain launches (default) or a captured graph for the gradient part of the step")
     ap.add_argument("--dqn-dp-emulate", action="store_true", help="N = 1: run the data-parallel step structure (no collective) to time it")
     ap.add_argument("--dqn-block", type=int, default=8, help="N = 1: training steps per hipGraphLaunch when no target-sync coin of the block fires (1 = one graph launch per step)")

@@ -387,9 +387,9 @@ class GraphedDqnLoop:
     a block with a firing coin runs step by step with the sync where the reference has it.  Same coin stream, same minibatch
     stream (device counter), same arithmetic: results equal the step-by-step loop's bit for bit."""
 
-    def __init__(self, agent, replay, B, draw_seed, block=8):
+    def __init__(self, agent, replay, B, draw_seed, block=8, draw_state=None):
         self.agent, self.block = agent, int(block)
-        self.one = CapturedDqnStep(agent, replay, B, fused=True, draw_seed=draw_seed)
+        self.one = CapturedDqnStep(agent, replay, B, fused=True, draw_seed=draw_seed, draw_state=draw_state)
         self.many = CapturedDqnStep(agent, replay, B, fused=True, draw_state=self.one.draw, steps=self.block) if self.block > 1 else None
         self.launches = 0
         self.syncs = 0
@@ -413,3 +413,61 @@ class GraphedDqnLoop:
                         self.syncs += 1
             done += k
         return loss
+
+
+class LeanDqnLoop:
+    """The same loop from PLAIN launches out of preallocated buffers: draw + gather, loss + gradients (8 kernels), clamp + Adam,
+    coin — ten launches per step, no graph.  With the launch chain this short the host keeps ahead of the GPU (~190 us of GPU
+    work per step) and the step loses the bubble that separates two graph launches; on a loaded host the captured loop is the
+    safer choice (``AutoDqnLoop`` measures).  Same arithmetic, same coin and minibatch streams: bit-identical to the other loops."""
+
+    def __init__(self, agent, replay, B, draw_seed, draw_state=None):
+        self.agent, self.replay, self.B = agent, replay, B
+        self.draw = draw_state if draw_state is not None else replay.draw_state(draw_seed)
+        self.bufs = None
+        self.syncs = 0
+
+    def run(self, n):
+        a, loss = self.agent, None
+        for _ in range(n):
+            self.bufs = self.replay.sample_drawn(self.B, self.draw, out=self.bufs)
+            loss = a.loss_and_grads(self.bufs)
+            a.optimizer.step()
+            if np.random.random() < a.update_rate:
+                a.sync_target()
+                self.syncs += 1
+        return loss
+
+
+class AutoDqnLoop:
+    """Runs the first steps once through each launch mode (captured blocks / plain launches), timed, and the rest through the
+    faster one.  The probe steps are ordinary training steps and the modes are bit-identical, so the trajectory does not depend
+    on the choice."""
+
+    def __init__(self, agent, replay, B, draw_seed, block=8, probe=256):
+        self.agent, self.probe = agent, int(probe)
+        self.lean = LeanDqnLoop(agent, replay, B, draw_seed)
+        self.graphed = GraphedDqnLoop(agent, replay, B, draw_seed, block=block, draw_state=self.lean.draw)
+        self.choice, self.probe_us = None, {}
+
+    def run(self, n):
+        import time
+        dev = torch.device(self.agent.device)
+        loss = None
+        if self.choice is None and n >= 2 * self.probe:
+            for name, loop in (("graph", self.graphed), ("plain", self.lean), ("graph", self.graphed), ("plain", self.lean)):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                loss = loop.run(self.probe // 2)
+                torch.cuda.synchronize(dev)
+                self.probe_us[name] = min(self.probe_us.get(name, 1e30), (time.perf_counter() - t0) / (self.probe // 2) * 1e6)
+            self.choice = min(self.probe_us, key=self.probe_us.get)
+            n -= 2 * self.probe
+        loop = self.lean if self.choice == "plain" else self.graphed
+        if n > 0:
+            loss = loop.run(n)
+        return loss
+
+    @property
+    def syncs(self):
+        return self.lean.syncs + self.graphed.syncs

@@ -265,6 +265,19 @@ def test_blocked_graph_loop_equals_the_step_by_step_loop(dev):
         assert torch.equal(blk.optimizer.state[k], ref.optimizer.state[k]), k
     assert torch.equal(blk.policy_net.flat, ref.policy_net.flat) and torch.equal(blk.target_net.flat, ref.target_net.flat)
     assert torch.equal(loop.one.loss, one.loss)
+    # ... and so do plain launches (LeanDqnLoop) and the loop that probes both modes before settling on one (AutoDqnLoop)
+    from ivos_w_amd.models.agent import AutoDqnLoop, LeanDqnLoop
+    for make, steps in ((lambda a: LeanDqnLoop(a, rp, B, draw_seed=seed), (n,)), (lambda a: AutoDqnLoop(a, rp, B, draw_seed=seed, block=8, probe=8), (33, n - 33))):
+        other = fresh()
+        np.random.seed(5)
+        lp = make(other)
+        for k in steps:
+            lp.run(k)
+        assert lp.syncs == syncs and other.optimizer.state["step"] == n
+        assert torch.equal(other.policy_net.flat, ref.policy_net.flat) and torch.equal(other.target_net.flat, ref.target_net.flat)
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(other.optimizer.state[k], ref.optimizer.state[k]), k
+    assert lp.choice in ("graph", "plain") and set(lp.probe_us) == {"graph", "plain"}
 
 
 def test_update_agent_none(dev, capsys):
