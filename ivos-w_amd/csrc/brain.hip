@@ -526,6 +526,213 @@ __global__ __launch_bounds__(512) void lstm_fwd_mfma_pair_kernel(LstmFwdPair pr)
     lstm_fwd_mfma_body(pr.j[which], (int)blockIdx.x - (which ? pr.first1 : 0));
 }
 
+// ---------------------------------------------------------------- recurrence + decoder in one kernel ("sample-pair" layout)
+// A workgroup owns BOTH directions of TWO samples (rows: (fw, n0) (bw, n0) (fw, n1) (bw, n1)) instead of four rows of one
+// direction, so when the recurrence ends it holds [h_fw | h_bw] of its samples' frames — the decoder's input — in LDS and
+// runs relu -> decoder_fc1 -> relu -> decoder_fc2 on them itself (the W_hh registers are free by then): the decoder launch
+// and the round trip of hs through memory are gone.  Same recurrence arithmetic as lstm_fwd_mfma_kernel; the decoder is
+// dec_fused_kernel's (16x16x4 MFMAs, a wave owns 16 output columns).  hs goes to memory only for the samples a consumer
+// reads them from (the loss rows of the policy's `state` half).
+struct FwdMega {
+    const float* prm;
+    const float* gx;            // [N,T,512]
+    float* hs;                  // [N,T,256], written for samples >= hs_from
+    float *gates, *cs, *hprev;  // kept for samples >= keep_from (nullable)
+    float* d1;                  // [N*T,128], written for samples >= keep_from
+    float* q;                   // [N*T]
+    int N, T, keep_from, hs_from;
+    int dbg;
+};
+struct FwdMegaPair {
+    FwdMega j[2];
+    int first1;
+};
+constexpr int MEGA_HLD = 2 * HD + 4;                                  // padded [h_fw | h_bw] row in LDS
+static size_t mega_lds_bytes(int T) { return (size_t)2 * T * MEGA_HLD * sizeof(float); }      // dynamic part: the pair's hs rows
+
+__global__ __launch_bounds__(512) void brain_fwd_mega_kernel(FwdMegaPair pr) {
+    extern __shared__ __attribute__((aligned(16))) float mega_lds[];
+    constexpr int R = 4, HP = HD + 4;
+    const int which = (int)blockIdx.x >= pr.first1;
+    const FwdMega& p = pr.j[which];
+    const int bid = (int)blockIdx.x - (which ? pr.first1 : 0);
+    __shared__ __attribute__((aligned(16))) float h_s[2][R][HP];
+    __shared__ float q_s[8][64];
+    float (*hs_l)[MEGA_HLD] = reinterpret_cast<float (*)[MEGA_HLD]>(mega_lds);     // [2T][260]: row a*T + t of sample a
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 3, j = wave * 16 + (lane >> 2);      // gate q of hidden unit j; after the transpose: row q
+    const float* __restrict__ prm = p.prm;
+    float w[HD];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(prm + O_WHH + (size_t)(q * HD + j) * HD);
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+            const float4 v = wp[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    }
+    for (int i = tid; i < 2 * R * HP; i += 512) (&h_s[0][0][0])[i] = 0.f;
+    __syncthreads();
+    const float gk = (q == 2) ? 2.0f : 1.0f;
+    const int Nk = p.N - p.keep_from;
+    int dd[R], nn[R];
+    bool ok[R], keep[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = 2 * bid + (r >> 1);
+        ok[r] = n < p.N;
+        nn[r] = ok[r] ? n : p.N - 1;
+        dd[r] = r & 1;
+        keep[r] = ok[r] && p.gates && nn[r] >= p.keep_from;
+    }
+    const int my_a = q >> 1, my_d = q & 1;                    // this lane's row after the transpose: sample my_a of the pair, direction my_d
+    const int my_n = 2 * bid + my_a;
+    const bool my_ok = my_n < p.N;
+    const bool my_keep = my_ok && p.gates && my_n >= p.keep_from;
+    const bool my_hs = my_ok && my_n >= p.hs_from;
+    const bool q_odd = (q & 1) != 0, q_hi = (q & 2) != 0;
+    float cq = 0.f;
+    float a_nx[R];
+    auto gx_fetch = [&](int s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int t = dd[r] ? p.T - 1 - s : s;
+            a_nx[r] = p.gx[((size_t)nn[r] * p.T + t) * 512 + q * HD + j];
+        }
+    };
+    gx_fetch(0);
+    for (int s = 0; s < p.T; ++s) {
+        const int cur = s & 1;
+        float a_cur[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a_cur[r] = a_nx[r];
+        if (s + 1 < p.T) gx_fetch(s + 1);
+        f32x4v acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        const float* hrow = &h_s[cur][q][0];
+        float4 hb[2][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hb[0][i] = *reinterpret_cast<const float4*>(hrow + 4 * i);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hb[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(hrow + 4 * (8 * (g + 1) + i));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kc = 8 * g + i;
+                const float4 h4 = hb[g & 1][i];
+                acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.x, w[4 * kc], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.y, w[4 * kc + 1], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.z, w[4 * kc + 2], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(h4.w, w[4 * kc + 3], acc[3], 0, 0, 0);
+            }
+        }
+        float m0[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float pre = ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + a_cur[r];
+            const float sg = fast_rcp(1.0f + fast_exp(-gk * pre));
+            m0[r] = fmaf(sg, gk, 1.0f - gk);
+        }
+        float m1[R], m2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float x = QuadDpp::mov<0xB1>(m0[r ^ 1]);
+            m1[r] = (((r & 1) != 0) == q_odd) ? m0[r] : x;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float x = QuadDpp::mov<0x4E>(m1[r ^ 2]);
+            m2[r] = (((r & 2) != 0) == q_hi) ? m1[r] : x;
+        }
+        cq = fmaf(m2[1], cq, m2[0] * m2[2]);
+        const float hq = m2[3] * fast_tanh(cq);
+        const int tq = my_d ? p.T - 1 - s : s;
+        if (my_ok) {
+            const float hold = h_s[cur][q][j];
+            h_s[cur ^ 1][q][j] = hq;
+            hs_l[my_a * p.T + tq][my_d * HD + j] = hq;
+            if (my_hs) p.hs[((size_t)my_n * p.T + tq) * 256 + my_d * HD + j] = hq;
+            if (my_keep) {
+                const size_t base = ((size_t)my_d * Nk + (my_n - p.keep_from)) * p.T + tq;
+                p.hprev[base * HD + j] = hold;
+                p.cs[base * HD + j] = cq;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (keep[r]) {
+                const int t = dd[r] ? p.T - 1 - s : s;
+                const size_t base = ((size_t)dd[r] * Nk + (nn[r] - p.keep_from)) * p.T + t;
+                p.gates[base * 512 + q * HD + j] = m0[r];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- decoder on the pair's 2 T rows (row m = a * T + t), 64 rows at a time; wave w owns output columns [16 w, 16 w + 16)
+    if (p.dbg) return;
+    const int m16 = lane & 15, kq = lane >> 4;
+    const int M = (2 * bid + 1 < p.N ? 2 : 1) * p.T;
+    float4 w3r[16];
+    {
+        const float* wb = prm + O_W3 + (size_t)(16 * wave + m16) * 256 + 4 * kq;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) w3r[c] = *reinterpret_cast<const float4*>(wb + 16 * c);
+    }
+    const float b3v = prm[O_B3 + 16 * wave + m16], w4v = prm[O_W4 + 16 * wave + m16], b4v = prm[O_B4];
+    for (int g0 = 0; g0 < M; g0 += 64) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* arow[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) arow[mt] = &hs_l[min(g0 + mt * 16 + m16, M - 1)][4 * kq];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float4 a[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float4 v = *reinterpret_cast<const float4*>(arow[mt] + 16 * c);
+                a[mt] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            }
+            const float4 b = w3r[c];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA16(a[mt].x, b.x, acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA16(a[mt].y, b.y, acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA16(a[mt].z, b.z, acc[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA16(a[mt].w, b.w, acc[mt]);
+        }
+        const int col = 16 * wave + m16;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = g0 + mt * 16 + 4 * kq + r;
+                const float v = fmaxf(acc[mt][r] + b3v, 0.f);
+                if (m < M) {
+                    const int n = 2 * bid + m / p.T, t = m - (m / p.T) * p.T;
+                    if (p.d1 && n >= p.keep_from) p.d1[((size_t)n * p.T + t) * HD + col] = v;
+                }
+                const float sum = row16_sum(v * w4v);
+                if (m16 == 0) q_s[wave][mt * 16 + 4 * kq + r] = sum;
+            }
+        __syncthreads();
+        if (tid < 64 && g0 + tid < M) {
+            const int m = g0 + tid, a = m / p.T;
+            p.q[((size_t)(2 * bid + a)) * p.T + (m - a * p.T)] =
+                (((q_s[0][tid] + q_s[1][tid]) + (q_s[2][tid] + q_s[3][tid])) + ((q_s[4][tid] + q_s[5][tid]) + (q_s[6][tid] + q_s[7][tid]))) + b4v;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- backward recurrence (BPTT)
 struct LstmBwd {
     const float* whh;    // [512,128]
@@ -827,6 +1034,26 @@ static void brain_forward_fused(const FwdPass* f, int n, int T, hipStream_t st) 
     }
     eg.first1 = dg.first1 = tiles[0];
     hipLaunchKernelGGL(enc_fused_kernel, dim3(tiles[0] + tiles[1]), dim3(256), 0, st, eg, O_W1, O_B1, O_W2, O_B2, O_WIH);
+    // recurrence + decoder in one kernel (FWD_MEGA, default OFF: measured 201 us per DQN step against 185.5 us for the separate
+    // decoder launch - the decoder's 16 us run on 192 workgroups after their recurrences instead of on the whole chip) when every
+    // pass is batched enough for the MFMA recurrence and the pair's 2 T rows of [h_fw | h_bw] fit LDS
+    bool mega = tune_get("FWD_MEGA", 0) && tune_get("LSTM_MFMA", 1) && mega_lds_bytes(T) <= 150 * 1024;
+    for (int i = 0; i < n; ++i) mega = mega && 2 * f[i].N >= 8;
+    if (mega) {
+        static std::once_flag once;
+        std::call_once(once, [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brain_fwd_mega_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); (void)hipGetLastError(); });
+        FwdMegaPair mp{};
+        int wgs[2] = {0, 0};
+        for (int i = 0; i < n; ++i) {
+            const FwdBufs& b = *f[i].b;
+            const int keep_from = b.gates ? b.keep_from : f[i].N;
+            mp.j[i] = FwdMega{f[i].prm, b.gx, b.hs, b.gates, b.cs, b.hprev, b.d1, b.q, f[i].N, T, keep_from, keep_from, tune_get("MEGA_DBG", 0)};
+            wgs[i] = (f[i].N + 1) / 2;
+        }
+        mp.first1 = wgs[0];
+        hipLaunchKernelGGL(brain_fwd_mega_kernel, dim3(wgs[0] + wgs[1]), dim3(512), mega_lds_bytes(T), st, mp);
+        return;
+    }
     if (n == 2) {
         LstmFwdPair pr{};
         pr.j[0] = lstm_fwd_args(f[0], T);

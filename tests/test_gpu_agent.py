@@ -360,7 +360,7 @@ def test_entry_points_run_on_the_buffers_device_not_the_current_one(dev):
     assert b"not a device pointer" in L.lib().ivosw_last_error()
 
 
-@pytest.mark.parametrize("tun", [dict(LSTM_QUAD=0), dict(DQN_GROUP=0), dict(DQN_FUSED=0), dict(DQN_TAIL=0), dict(DQN_FUSED=0, DQN_TAIL=0), dict(LSTM_QUAD=0, DQN_GROUP=0, DQN_STREAMS=0)])
+@pytest.mark.parametrize("tun", [dict(LSTM_QUAD=0), dict(DQN_GROUP=0), dict(DQN_FUSED=0), dict(FWD_MEGA=1), dict(DQN_TAIL=0), dict(DQN_FUSED=0, DQN_TAIL=0), dict(LSTM_QUAD=0, DQN_GROUP=0, DQN_STREAMS=0)])
 def test_alternative_kernel_paths_agree_with_the_default(dev, tun):
     """The round-1 recurrences (LSTM_QUAD=0: gate column per thread, two barriers per step) and the ungrouped two-stream backward
     tail (DQN_GROUP=0) stay in the library as tunables: same step, different summation orders — loss and every gradient tensor
