@@ -23,6 +23,10 @@ bottlenecks / stage runs fused) (bound: bf16 MFMA, 2.5 PFLOP/s dense).  achieved
 average launch duration, where the family's time is measured INSIDE the timed region with one HIP-event pair per forward pass
 on the launch stream (ivosw_profile_span_*: stem .. last res5 kernel; the bbox / ROI kernels before and the pool+fc kernel after
 are outside the pair), so family time <= ms_per_step by construction and nothing is bracketed per launch.
+`roofline.traffic`: HBM bytes per launch of that family MEASURED IN THIS RUN (N = 1): after the timed region the same forward is
+re-run in two child processes under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (live_traffic(); counters only, ~10 s); if
+rocprofv3 is missing or a child fails, the committed summary of the same passes (profiles/pmc_traffic_latest.json) is quoted and
+`traffic_source` says so.
 `checked`: after the timed region a sample of the B=256 scores is compared with the oracle on the CPU (and the fp32 parity
 mode, which is also timed: `fp32`); the line is not printed if they disagree.  cpu_baseline: torch-CPU restatements of the
 reference path (kind "port") on bounded samples, rank 0, N=1 only.
@@ -164,6 +168,57 @@ def check_scores(scores, tf, tp, precision, pick):
     if not (err <= tol):
         raise SystemExit(f"bench.py: scores of the timed batch disagree with the oracle (worst rel err {err:.3e} > {tol}): no line printed")
     return {"frames": len(pick), "worst_rel_err": float(f"{err:.3e}"), "tolerance": tol, "against": "oracle/assess_oracle.py (torch-CPU restatement of AssessNet.forward)"}
+
+
+def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=150):
+    """roofline.traffic measured in THIS run: the same forward (batch 256, bf16, default chunk) is re-run in two child processes
+    under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only - no trace domains), after the
+    timed region, and the per-kernel counters of the tower family are summed exactly as tools/pmc_summary.py does for the
+    committed profiles (KiB units, FETCH_SIZE x 2 on gfx950).  Returns None (the committed summary stays quoted) when
+    rocprofv3 is missing, a child fails or times out, or the launch count does not match the timed run."""
+    import glob
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):      # never nest profilers
+        return None
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    fams = [f.strip("*") for f in family.split("|")]
+    tmp = tempfile.mkdtemp(prefix="ivosw_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "-d", d, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--tower-only", "--steps", str(passes - 1), "--warmup", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            csvs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not csvs:
+                return None
+            agg = pmc.load(csvs[0], counter)
+            n = sum(v[0] for k, v in agg.items() if any(f in k for f in fams))
+            kib = sum(v[1] for k, v in agg.items() if any(f in k for f in fams))
+            got[counter] = (n, kib * 1024.0)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    (nf, rd), (nw, wr) = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    rd *= 2.0                                              # gfx950: FETCH_SIZE reports half the bytes of wide streaming reads
+    if nf != nw or nf != launches_per_pass * passes:
+        return None
+    per_pass = (rd + wr) / passes
+    return {"traffic": round((rd + wr) / nf), "traffic_bytes_per_step": round(per_pass),
+            "traffic_read_write_GB_per_step": [round(rd / passes / 1e9, 3), round(wr / passes / 1e9, 3)],
+            "traffic_source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child runs of `bench.py --tower-only`, {passes} forward passes "
+                              f"each, {nf} launches of the family; FETCH_SIZE x2 gfx950 correction, KiB units), {round(time.perf_counter() - t0)} s",
+            "hbm_GBps_of_family": round(per_pass / (conv_ms * 1e-3) / 1e9, 1) if conv_ms > 0 else None}
 
 
 def bench_assess(args, rank, world, dev, dist):
@@ -566,6 +621,8 @@ def main():
     ap.add_argument("--dqn-block", type=int, default=8, help="N = 1: training steps per hipGraphLaunch when no target-sync coin of the block fires (1 = one graph launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-report", default="", help="write a per-conv-layer timing table (HIP events) to this file")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not re-run the forward under rocprofv3 --pmc for roofline.traffic (the committed PMC summary is quoted instead)")
+    ap.add_argument("--tower-only", action="store_true", help="(internal: the rocprofv3 --pmc sub-runs) build the inputs, run warmup + steps forward passes, print nothing else")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
@@ -576,10 +633,21 @@ def main():
     if lib.ivosw_ablation_build() != 0 or os.environ.get("IVOSW_DEBUG_CONV", "0") not in ("", "0") or os.environ.get("IVOSW_TUNE_BDBG", "0") not in ("", "0"):
         raise SystemExit("bench.py: ablation switches are compiled in or set (IVOSW_ABLATION build / IVOSW_DEBUG_CONV / IVOSW_TUNE_BDBG): refusing to measure")
 
+    if args.tower_only:
+        net, tf, tp = build_assess(args, rank, dev)
+        for _ in range(args.warmup + args.steps):
+            net(tf, tp)
+        torch.cuda.synchronize(dev)
+        print(json.dumps({"tower_only_passes": args.warmup + args.steps}), flush=True)
+        return
     line = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic"}
     if args.workload == "assess":
         fps, dt, roof, extra = bench_assess(args, rank, world, dev, dist)
+        if rank == 0 and world == 1 and not args.no_live_traffic and args.batch == 256 and args.precision == "bf16" and not args.chunk:
+            live = live_traffic(roof["kernel"], roof["launches_per_step"], roof["kernel_ms_per_step"])
+            if live is not None:
+                roof.update(live)
         dqn_sps, dqn_dt, dqn_info = bench_dqn(args, rank, world, dev, dist, args.dqn_steps, 20)
         line.update({"metric": "assessed_frames_per_sec", "value": round(fps, 1), "unit": "frames/s",
                      "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": args.precision,

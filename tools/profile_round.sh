@@ -5,7 +5,7 @@ tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="python bench.py --steps 4 --warmup 1 --min-warm-s 0 --no-fp32 --no-cpu-baseline --dqn-steps 20"
+BENCH="python bench.py --steps 4 --warmup 1 --min-warm-s 0 --no-fp32 --no-cpu-baseline --no-live-traffic --dqn-steps 20"
 PASSES=5   # warmup 1 + timed 4 (the span timing runs inside the timed region; --no-fp32 keeps the fp32 conv_igemm launches out of the family)
 rocprofv3 --kernel-trace --stats -d $out/trace -o t -- $BENCH > $out/bench_trace.log 2>&1
 db=$(ls $out/trace/*.db 2>/dev/null | head -1)
