@@ -197,7 +197,14 @@ def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=150):
             d = os.path.join(tmp, counter)
             cmd = [prof, "--pmc", counter, "-d", d, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                    "--tower-only", "--steps", str(passes - 1), "--warmup", "1"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                child.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, 9)                    # the profiler AND the python it started (own session: exact group)
+                child.communicate()
+                return None
+            r = child
             csvs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not csvs:
                 return None
@@ -219,6 +226,48 @@ def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=150):
             "traffic_source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate child runs of `bench.py --tower-only`, {passes} forward passes "
                               f"each, {nf} launches of the family; FETCH_SIZE x2 gfx950 correction, KiB units), {round(time.perf_counter() - t0)} s",
             "hbm_GBps_of_family": round(per_pass / (conv_ms * 1e-3) / 1e9, 1) if conv_ms > 0 else None}
+
+
+def bench_front(args, dev, tf, tp):
+    """the assessment front end (mask -> box, ROI crop-resize + normalise) is HBM-bound - timed on its own through
+    the two C-ABI entry points on the timed batch; algorithmic bytes = `tp` once for the box pass, and for the crop the source
+    pixels inside each sample's box (3 frame planes + the mask plane, fp32) once + the ROI tile written once."""
+    lib = L.lib()
+    B, H, W = tp.shape
+    code = L.BF16 if args.precision == "bf16" else L.F32
+    yxhw = torch.empty(B, 4, device=dev, dtype=torch.float32)
+    scratch = torch.empty(B * 4, device=dev, dtype=torch.int32)
+    roi = torch.empty(B, 256, 256, 4, device=dev, dtype=torch.bfloat16 if args.precision == "bf16" else torch.float32)
+    st = L.stream_ptr(dev)
+
+    def bbox():
+        L.check(lib.ivosw_mask_bbox(L.dptr(tp), B, H, W, L.dptr(yxhw), L.dptr(scratch), st), "mask_bbox")
+
+    def crop():
+        L.check(lib.ivosw_roi_sample(L.dptr(tf), L.dptr(tp), L.dptr(yxhw), B, H, W, code, L.dptr(roi), st), "roi_sample")
+    out = {}
+    for name, fn in (("bbox", bbox), ("roi", crop)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 30
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out[name] = e0.elapsed_time(e1) * 1e3 / n
+    box = yxhw.cpu().numpy().astype(np.float64)
+    hh = np.clip(np.minimum(box[:, 0] + box[:, 2] / 2, H) - np.maximum(box[:, 0] - box[:, 2] / 2, 0), 0, H)      # (y, x) = box centre
+    ww = np.clip(np.minimum(box[:, 1] + box[:, 3] / 2, W) - np.maximum(box[:, 1] - box[:, 3] / 2, 0), 0, W)
+    bytes_bbox = float(B) * H * W * 4
+    bytes_roi = float(np.sum(hh * ww) * 4 * 4) + float(B) * 256 * 256 * 4 * roi.element_size()
+    us = out["bbox"] + out["roi"]
+    ach = (bytes_bbox + bytes_roi) / (us * 1e-6) / 1e9
+    return {"kernels": "bbox_scan|bbox_finalize|roi_sample", "us_per_step": round(us, 1), "bbox_us": round(out["bbox"], 1), "roi_us": round(out["roi"], 1),
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                         "bbox_GBps": round(bytes_bbox / (out["bbox"] * 1e-6) / 1e9, 1), "roi_GBps": round(bytes_roi / (out["roi"] * 1e-6) / 1e9, 1),
+                         "note": "algorithmic bytes: tp read once by the box pass; box pixels of 3 frame planes + mask (fp32) read once and the 256x256x4 tile written once by the crop (the box is clipped to the frame)"}}
 
 
 def bench_assess(args, rank, world, dev, dist):
@@ -289,6 +338,7 @@ def bench_assess(args, rank, world, dev, dist):
         pick = [0, 37, 74, 111, 148, 185, 222, args.batch - 1] if args.batch >= 256 else list(range(min(8, args.batch)))
         extra["checked"] = True
         extra["check"] = check_scores(scores, tf, tp, args.precision, pick)
+        extra["front"] = bench_front(args, dev, tf, tp)
         if args.precision == "bf16" and not args.no_fp32:
             extra["fp32"] = bench_fp32(args, dev, tf, tp, scores, pick)
     return fps, dt, roof, extra

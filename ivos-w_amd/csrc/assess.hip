@@ -6,6 +6,7 @@
 // ~7 TB/s against ~6 TB/s from HBM (tools/ubench/dma_bench), while small launches cost occupancy, so the bf16
 // default is as large as the benchmark batch.  In bf16 mode the stride-1 bottlenecks of res2 run as ONE fused kernel
 // each (bottleneck.hip); everything else is layer by layer (conv.hip).
+#include <limits.h>
 #include <algorithm>
 #include <vector>
 
@@ -296,6 +297,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
     IVOSW_ON_DEVICE_OF(scores);
     IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
+    IVOSW_REQUIRE((long)H * W <= INT_MAX, "frame too large (H * W <= INT_MAX)");
     IVOSW_REQUIRE(tap_stage >= 0 && tap_stage <= 8, "tap_stage out of range");
     IVOSW_REQUIRE(tap_stage == 0 || tap_out, "tap_out is null");
     const bool want_split = split_wanted(dtype, B, chunk, tap_stage);

@@ -109,12 +109,25 @@ __device__ __forceinline__ float lin_m1_1(int j, int n) {  // torch.linspace(-1,
     return (j < n / 2) ? __fadd_rn(-1.0f, __fmul_rn((float)j, step)) : __fsub_rn(1.0f, __fmul_rn((float)(n - 1 - j), step));
 }
 
-// grid (256 rows, B), block 256 (one output pixel per thread): roi[b][i][j][0..3] = (R,G,B normalised, P)
+// grid B * 256 / ROI_R, block 256: thread j owns output column j of ROI_R consecutive output rows of one sample,
+// roi[b][i][j][0..3] = (R,G,B normalised, P).  Everything that depends on the sample and the column only (theta, the source
+// x, its two taps, their weights and validity) is computed once per thread instead of once per output pixel, and the rows are
+// processed two at a time (32 gathers in flight): one output pixel per thread ran ~250 vector instructions for 16 loads and
+// 8 B of output, VALU-bound at 180 us per 256 frames.  Per pixel the arithmetic and its order are unchanged.
+constexpr int ROI_R = 8;
+// two neighbouring fp32 pixels with one 8-byte load from a 4-byte-aligned address (global memory takes unaligned dwordx2)
+struct __attribute__((packed, aligned(4))) PairF32 { float x, y; };
+__device__ __forceinline__ float2 ld_pair(const float* p) {
+    const PairF32 v = *reinterpret_cast<const PairF32*>(p);
+    return make_float2(v.x, v.y);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict__ tf, const float* __restrict__ tp,
                                                          const float* __restrict__ yxhw, int b0, SampleMap sm, int H, int W, RoiNorm nrm,
                                                          T* __restrict__ roi) {
-    const int b = blockIdx.y, i = blockIdx.x, j = threadIdx.x;     // yxhw / roi rows are local to the launch
+    constexpr int GPS = 256 / ROI_R;                               // row groups per sample
+    const int b = blockIdx.x / GPS, i0 = (blockIdx.x % GPS) * ROI_R, j = threadIdx.x;     // yxhw / roi rows are local to the launch
     const int bg = b0 + b, fr = bg % sm.n_frames;
     const float ry = yxhw[b * 4 + 0], rx = yxhw[b * 4 + 1], rh = yxhw[b * 4 + 2], rw = yxhw[b * 4 + 3];
     // get_ROI_grid (assessment.py:79-92), fp32, same operation order as the reference.  NOTE: HIP's __fmul_rn / __fadd_rn
@@ -128,61 +141,85 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict
     const float t11 = __fsub_rn(ymax, ymin) / hm, t12 = __fsub_rn(__fadd_rn(ymin, ymax), hm) / hm;
     // affine_grid + grid_sample(align_corners=True): pixel = ((g + 1) / 2) * (size - 1)
     const float gx = __fadd_rn(__fmul_rn(lin_m1_1(j, 256), t00), t02);
-    const float gy = __fadd_rn(__fmul_rn(lin_m1_1(i, 256), t11), t12);
     const float sx = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.0f), 0.5f), wm);
-    const float sy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.0f), 0.5f), hm);
-    const float x0f = floorf(sx), y0f = floorf(sy);
-    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float x0f = floorf(sx);
+    const int x0 = (int)x0f;
     const float wx1 = __fsub_rn(sx, x0f), wx0 = __fsub_rn(__fadd_rn(x0f, 1.0f), sx);
-    const float wy1 = __fsub_rn(sy, y0f), wy0 = __fsub_rn(__fadd_rn(y0f, 1.0f), sy);
-    const float w_nw = __fmul_rn(wx0, wy0), w_ne = __fmul_rn(wx1, wy0), w_sw = __fmul_rn(wx0, wy1), w_se = __fmul_rn(wx1, wy1);
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
-    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
-    const size_t plane = (size_t)H * W;
     // All 16 taps are loaded unconditionally from clamped addresses and out-of-range taps get weight 0 (zero padding:
     // they contribute +0, which leaves the fp32 sum bit-identical): predicated loads made hipcc branch around every
     // load and wait for it, 16 dependent round trips per pixel.
-    const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
-    const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
-    const size_t o00 = (size_t)yc0 * W + xc0, o01 = (size_t)yc0 * W + xc1, o10 = (size_t)yc1 * W + xc0, o11 = (size_t)yc1 * W + xc1;
-    const float k_nw = (vy0 && vx0) ? w_nw : 0.f, k_ne = (vy0 && vx1) ? w_ne : 0.f;
-    const float k_sw = (vy1 && vx0) ? w_sw : 0.f, k_se = (vy1 && vx1) ? w_se : 0.f;
-    float v[4][4];
+    // The two x taps of a row are neighbours in memory: ONE 8-byte load at xb = clamp(x0, 0, W - 2) brings both (the texture-
+    // cache access count, ~19 per gathered dword load of a wave, bounds this kernel - rocprofv3 TCP_TOTAL_CACHE_ACCESSES).
+    // At the frame's edges one of the taps has weight 0 and takes whichever in-range pixel the pair holds.
+    const int xb = min(max(x0, 0), W - 2);
+    const bool t0_hi = x0 >= W - 1, t1_lo = x0 < 0;                // tap0 = pair.y at the right edge, tap1 = pair.x at the left edge
+    const size_t plane = (size_t)H * W;
+    const float* src[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float* src = (c < 3) ? tf + ((size_t)fr * 3 + c) * plane
-                                   : tp + (size_t)(bg / sm.n_frames) * sm.stride_obj + (size_t)fr * sm.stride_frame;
-        v[c][0] = src[o00]; v[c][1] = src[o01]; v[c][2] = src[o10]; v[c][3] = src[o11];
+    for (int c = 0; c < 3; ++c) src[c] = tf + ((size_t)fr * 3 + c) * plane;
+    src[3] = tp + (size_t)(bg / sm.n_frames) * sm.stride_obj + (size_t)fr * sm.stride_frame;
+    float mu[3], sd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {      // (f - mean) / std after the zero pad (assessment.py:47)
+        mu[c] = nrm.dev ? nrm.dev[c] : nrm.mean[c];
+        sd[c] = nrm.dev ? nrm.dev[3 + c] : nrm.std[c];
     }
-    float out[4];
+    T* dst = roi + (((size_t)b * 256 + i0) * 256 + j) * 4;
+#pragma unroll 1
+    for (int r0 = 0; r0 < ROI_R; r0 += 2) {
+        float v[2][4][4], k[2][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float acc = 0.f;
-        acc = __fadd_rn(acc, __fmul_rn(v[c][0], k_nw));
-        acc = __fadd_rn(acc, __fmul_rn(v[c][1], k_ne));
-        acc = __fadd_rn(acc, __fmul_rn(v[c][2], k_sw));
-        acc = __fadd_rn(acc, __fmul_rn(v[c][3], k_se));
-        if (c < 3) {  // (f - mean) / std after the zero pad (assessment.py:47)
-            const float mu = nrm.dev ? nrm.dev[c] : nrm.mean[c], sd = nrm.dev ? nrm.dev[3 + c] : nrm.std[c];
-            acc = __fsub_rn(acc, mu) / sd;
+        for (int rr = 0; rr < 2; ++rr) {
+            const int i = i0 + r0 + rr;
+            const float gy = __fadd_rn(__fmul_rn(lin_m1_1(i, 256), t11), t12);
+            const float sy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.0f), 0.5f), hm);
+            const float y0f = floorf(sy);
+            const int y0 = (int)y0f;
+            const float wy1 = __fsub_rn(sy, y0f), wy0 = __fsub_rn(__fadd_rn(y0f, 1.0f), sy);
+            const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+            const int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y0 + 1, 0), H - 1);
+            const int o0 = yc0 * W + xb, o1 = yc1 * W + xb;        // < H * W <= INT_MAX (checked by the host)
+            const float w_nw = __fmul_rn(wx0, wy0), w_ne = __fmul_rn(wx1, wy0), w_sw = __fmul_rn(wx0, wy1), w_se = __fmul_rn(wx1, wy1);
+            k[rr][0] = (vy0 && vx0) ? w_nw : 0.f; k[rr][1] = (vy0 && vx1) ? w_ne : 0.f;
+            k[rr][2] = (vy1 && vx0) ? w_sw : 0.f; k[rr][3] = (vy1 && vx1) ? w_se : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float2 p0 = ld_pair(src[c] + o0), p1 = ld_pair(src[c] + o1);
+                v[rr][c][0] = t0_hi ? p0.y : p0.x; v[rr][c][1] = t1_lo ? p0.x : p0.y;
+                v[rr][c][2] = t0_hi ? p1.y : p1.x; v[rr][c][3] = t1_lo ? p1.x : p1.y;
+            }
         }
-        out[c] = acc;
-    }
-    T* dst = roi + (((size_t)b * 256 + i) * 256 + j) * 4;
-    if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
-    } else {
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2_bf16(out[0], out[1]), pack2_bf16(out[2], out[3]));
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float out[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float acc = 0.f;
+                acc = __fadd_rn(acc, __fmul_rn(v[rr][c][0], k[rr][0]));
+                acc = __fadd_rn(acc, __fmul_rn(v[rr][c][1], k[rr][1]));
+                acc = __fadd_rn(acc, __fmul_rn(v[rr][c][2], k[rr][2]));
+                acc = __fadd_rn(acc, __fmul_rn(v[rr][c][3], k[rr][3]));
+                if (c < 3) acc = __fsub_rn(acc, mu[c]) / sd[c];
+                out[c] = acc;
+            }
+            T* d = dst + (size_t)(r0 + rr) * 256 * 4;
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(d) = make_float4(out[0], out[1], out[2], out[3]);
+            } else {
+                *reinterpret_cast<uint2*>(d) = make_uint2(pack2_bf16(out[0], out[1]), pack2_bf16(out[2], out[3]));
+            }
+        }
     }
 }
 
 void launch_roi_sample(const float* tf, const float* tp, const float* yxhw, int b0, int B, int H, int W, int dtype,
                        const SampleMap& sm, const RoiNorm& nrm, void* roi, hipStream_t st) {
     if (dtype == IVOSW_F32)
-        hipLaunchKernelGGL(roi_sample_kernel<float>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, b0, sm, H, W, nrm,
+        hipLaunchKernelGGL(roi_sample_kernel<float>, dim3(B * (256 / ROI_R)), dim3(256), 0, st, tf, tp, yxhw, b0, sm, H, W, nrm,
                            static_cast<float*>(roi));
     else
-        hipLaunchKernelGGL(roi_sample_kernel<bf16_t>, dim3(256, B), dim3(256), 0, st, tf, tp, yxhw, b0, sm, H, W, nrm,
+        hipLaunchKernelGGL(roi_sample_kernel<bf16_t>, dim3(B * (256 / ROI_R)), dim3(256), 0, st, tf, tp, yxhw, b0, sm, H, W, nrm,
                            static_cast<bf16_t*>(roi));
 }
 
@@ -205,6 +242,7 @@ extern "C" int ivosw_roi_sample(const float* tf, const float* tp, const float* y
     IVOSW_REQUIRE(tf && tp && yxhw && roi, "null pointer");
     IVOSW_ON_DEVICE_OF(roi);
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
+    IVOSW_REQUIRE((long)H * W <= INT_MAX && B <= (1 << 24), "frame or batch too large (H * W <= INT_MAX, B <= 2^24)");
     IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
     RoiNorm nrm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, nullptr};  // Encoder.mean/std (assessment.py:41-44)
     launch_roi_sample(tf, tp, yxhw, 0, B, H, W, dtype, SampleMap{B, (long)H * W, 0}, nrm, roi, as_stream(stream));
