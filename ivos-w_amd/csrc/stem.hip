@@ -85,11 +85,23 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
         *reinterpret_cast<uint4*>(lds + WL_OFF + i * 16) = *reinterpret_cast<const uint4*>(wpk + ((ch * 8 + ky) * 8 + 2 * q) * 4);
     }
     const int ct = wave & 1, pq = wave >> 1;      // conv: wave = (channel tile ct, pixel tiles pq, pq+2, .., pq+8)
+    // Pixel tile T of the 17 x 17 conv outputs (the MFMA's 32 pixel columns may be ANY 32 pixels): T < 8 is the 4-row x 8-column
+    // block (T >> 1, T & 1) of the 16 x 16 core, tile 8 is row 16 (17 pixels), tile 9 is column 16 (rows 0..15).  A conv row is
+    // PW = 40 sixteen-byte chunks of the patch, 40 = 8 (mod 16): the four 8-pixel row segments a 16-lane group of a ds_read_b128
+    // touches then fall on four different quarters of the 64 banks - conflict-free.  (32 CONSECUTIVE pixels of the 17-wide
+    // map wrap to the next row somewhere inside almost every lane group and read two chunks of the same banks.  rocprofv3, per
+    // 128 frames: SQ_LDS_BANK_CONFLICT 15.8 M -> 10.8 M cycles, SQ_LDS_IDX_ACTIVE 32.7 M -> 27.7 M; the launch time did not move
+    // (164 us per 256 frames either way): the kernel is bound by its ~820 non-MFMA vector instructions per tile, not by the LDS.)
+    auto tile_px = [&](int T, int& cy, int& cx) -> bool {
+        if (T < 8) { cy = 4 * (T >> 1) + (lrow >> 3); cx = 8 * (T & 1) + (lrow & 7); return true; }
+        if (T == 8) { cy = 16; cx = min(lrow, 16); return lrow <= 16; }
+        cy = min(lrow, 15); cx = 16; return lrow < 16;
+    };
     unsigned pb[5];                               // LDS address of this lane's pixel pair at (ky, tap half) = (0, 0)
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        const int p = min((pq + 2 * i) * 32 + lrow, NPIX - 1);
-        const int cy = p / CT, cx = p - cy * CT;
+        int cy, cx;
+        (void)tile_px(pq + 2 * i, cy, cx);       // padding lanes read a valid pixel, their results are dropped
         pb[i] = lds_base + PATCH_OFF + ((2 * cy) * PW + 2 * cx + 2 * kh) * 8;
     }
     const unsigned wb = lds_base + WL_OFF + (kh * 64 + ct * 32 + lrow) * 16;
@@ -139,9 +151,9 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
         // + bias, ReLU, zero outside the 128x128 conv map (pool padding: every window holds a valid value >= 0)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int p = (pq + 2 * i) * 32 + lrow;
-            if (p < NPIX) {
-                const int cyl = p / CT, cxl = p - cyl * CT;
+            int cyl, cxl;
+            if (tile_px(pq + 2 * i, cyl, cxl)) {
+                const int p = cyl * CT + cxl;
                 const int cy = 2 * py0 - 1 + cyl, cx = 2 * px0 - 1 + cxl;
                 const bool in = cy >= 0 && cy < 128 && cx >= 0 && cx < 128;
 #pragma unroll
