@@ -445,3 +445,40 @@ def test_two_stream_split_is_invisible_in_the_scores(dev, net16):
     finally:
         lib.ivosw_tune_set(b"STREAMS2", 1)
     assert torch.equal(s1, s0)
+
+
+def test_roi_crop_with_boxes_over_every_frame_border(dev):
+    """ivosw_roi_sample against the oracle's grid sampler for boxes that hang over each border and corner of the frame (the
+    clamp of all2yxhw allows 5 pixels outside), for a box wider than the frame and for tiny / odd frame sizes: the kernel takes the two
+    x taps of a row with one 8-byte load and picks, at the frame's edge, the in-range pixel for the tap whose partner is
+    zero-padded - the cases the golden batches only brush."""
+    from ivos_w_amd import _lib as L
+    from oracle import assess_oracle as ao
+    lib = L.lib()
+    mean = np.array([0.485, 0.456, 0.406], np.float32)[None, :, None, None]
+    std = np.array([0.229, 0.224, 0.225], np.float32)[None, :, None, None]
+    for (H, W) in ((480, 854), (37, 53), (2, 2)):
+        rs = np.random.RandomState(H * W)
+        boxes = np.array([[H / 2, W / 2, H + 10, W + 10],              # over all four borders (x0 = -5 .. W + 4)
+                          [20.0, 30.0, 60.0, 90.0],                     # top-left corner outside
+                          [H - 10.0, W - 12.0, 50.0, 70.0],             # bottom-right corner outside
+                          [H / 2, -2.0, 40.0, 9.0],                     # centred left of the frame
+                          [H / 2, W + 1.5, 33.0, 11.0],                 # centred right of the frame
+                          [H / 3, W / 3, 31.7, 47.3]], np.float32)      # inside
+        B = len(boxes)
+        tf = rs.rand(B, 3, H, W).astype(np.float32)
+        tp = rs.rand(B, H, W).astype(np.float32)
+        theta = ao.roi_theta(boxes, H, W)
+        want_f = (ao.roi_sample(tf, theta) - mean) / std
+        want_p = ao.roi_sample(tp[:, None], theta)
+        want = np.concatenate([want_f, want_p], 1).transpose(0, 2, 3, 1)          # NHWC4
+        d_tf, d_tp, d_box = (torch.from_numpy(a).to(dev) for a in (tf, tp, boxes))
+        roi = torch.empty(B, 256, 256, 4, device=dev, dtype=torch.float32)
+        L.check(lib.ivosw_roi_sample(L.dptr(d_tf), L.dptr(d_tp), L.dptr(d_box), B, H, W, L.F32, L.dptr(roi), L.stream_ptr(dev)), "roi_sample")
+        got = roi.cpu().numpy()
+        # sample points differ by fp32 contraction of theta * linspace + offset (DESIGN: <= 3e-4 on the tiles); values are O(1)
+        np.testing.assert_allclose(got, want, atol=2e-3 if min(H, W) > 2 else 5e-3, rtol=0)
+        r16 = torch.empty(B, 256, 256, 4, device=dev, dtype=torch.bfloat16)
+        L.check(lib.ivosw_roi_sample(L.dptr(d_tf), L.dptr(d_tp), L.dptr(d_box), B, H, W, L.BF16, L.dptr(r16), L.stream_ptr(dev)), "roi_sample")
+        # the same values rounded to bf16 (the two template instances may contract fp32 operations differently: one bf16 ulp)
+        np.testing.assert_allclose(r16.float().cpu().numpy(), got, rtol=2.0 ** -7, atol=1e-3)
