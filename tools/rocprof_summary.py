@@ -34,7 +34,25 @@ def main():
         f"where {like} group by s.kernel_name, d.grid_size_x order by 4 desc"))
     ft = sum(r[3] for r in rows)
     n = sum(r[2] for r in rows)
-    print(f"# family total {ft/1e6:.3f} ms, {n} launches, avg {ft/max(n,1)/1e3:.2f} us\n")
+    print(f"# family total {ft/1e6:.3f} ms, {n} launches, avg {ft/max(n,1)/1e3:.2f} us")
+    # With the two-stream split two launches of the family run side by side, so the sum of their durations counts that
+    # time twice: what bench.py's roofline uses (one HIP-event span per forward pass, latest end - earliest start over
+    # the two streams) is the WALL time during which a family kernel was running = the union of the dispatch intervals.
+    iv = sorted(cur.execute(
+        "select d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
+        f"where {like}"))
+    wall, cs, ce = 0, None, None
+    for a, b in iv:
+        if cs is None or a > ce:
+            if cs is not None:
+                wall += ce - cs
+            cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    if cs is not None:
+        wall += ce - cs
+    print(f"# family wall time (union of the {n} dispatch intervals) {wall/1e6:.3f} ms = {wall/max(n,1)/1e3:.2f} us per launch "
+          f"(compare bench.py roofline.avg_launch_us; overlap factor {ft/max(wall,1):.2f})\n")
     print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>9} {'pct':>6} {'blocks':>8}  instance")
     for r in rows:
         print(f"{r[2]:7d} {r[3]/1e6:10.3f} {r[4]/1e3:9.2f} {100*r[3]/ft:6.2f} {r[1]//256:8d}  {demangle(r[0])[:120]}")
