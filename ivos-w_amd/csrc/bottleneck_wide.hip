@@ -731,6 +731,313 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- res3, small tile: two workgroups per CU
+// bneck_halo_kernel<128> above runs ONE workgroup per CU: its memory phases (A: 360 KB x halo in, C: residual in / y out) and
+// its MFMA-bound phase B alternate (31 k + 27 k + 27 k cycles per tile) instead of overlapping.  Same dataflow on an 8 x 16-pixel
+// tile (10 x 18 halo = 180 rows = 6 pixel tiles): 75 KB of LDS and <= 128 VGPRs, so two workgroups share a CU and one sits in
+// the matrix cores while the other waits on memory (what bneck_halo64s_kernel does for res2).
+//   phase A  wave = (channel tile w & 3, pixel tiles 3 g .. 3 g + 2 of the 6 with g = w >> 2); x through a 3-slot LDS-DMA ring
+//   phase B  wave = (channel tile w & 3, pixel tiles 2 g, 2 g + 1 of the 4 output tiles), 18 steps (tap, slice) of 4 k-steps
+//   phase C  2 chunks x (8 channel tiles = 8 waves) x 4 pixel tiles, store pass through the per-wave staging tile
+// LDS: [0, 73728) ring (3 x 24 KB) -> t1 (2 slices x 192 rows) [0, 49152) -> t2 (2 x 128 rows) [0, 32768) | staging [32768, 65536);
+//      [73728, 76800) biases.  Per pixel the arithmetic and its order are those of bneck_halo_kernel<128> (bit-identical output).
+// MEASURED SLOWER and therefore off by default (tunable HALO128S=1 selects it; tests keep it bit-identical): 272 against 230 us per
+// block at B = 256 (tower 3.73 against 3.54 ms).  What works for res2 does not carry over: with C = 128 every wave re-streams ~1 MB of
+// weight fragments per tile from L2 through the texture cache (phase B alone 590 KB) - per 128 pixels now instead of per 256 -
+// which is ~16 k cache accesses per tile against ~19 k cycles of MFMA issue, the halo grows from 1.27 x to 1.41 x of the tile, and
+// the 128-VGPR budget of two workgroups per CU costs 31 spilled registers.
+__global__ __launch_bounds__(512, 4) void bneck_halo128s_kernel(BneckWideArgs p) {
+    constexpr int C = 128, CIN = 512, HW = 32, BTY = 8, BTX = 16, HTX = 18, HR = 180, MH = 192, NGA = 23;
+    constexpr int TPX = HW / BTX, TPF = (HW / BTY) * TPX;          // 2 tiles across, 8 per frame
+    constexpr int NSL = 2, NCT = 4, TPG = 3;
+    constexpr int SLOT = 24576;
+    constexpr int T1S = MH * ROWB, T2S = 128 * ROWB;
+    constexpr int STG_OFF = 32768, BIAS_OFF = 3 * SLOT, LDS_BYTES = BIAS_OFF + 6 * C * 4;       // 76800
+    static_assert(NSL * T1S <= 3 * SLOT && NSL * T2S <= STG_OFF && STG_OFF + 8 * 4096 <= 3 * SLOT && 2 * LDS_BYTES <= WIDE_LDS, "LDS map");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = L / TPF, tl = L - b * TPF;
+    const int y0 = (tl / TPX) * BTY, x0 = (tl % TPX) * BTX;
+    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * HW * HW * CIN;
+    bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * HW * HW * CIN;
+    const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
+    const int ctw = wave & 3, grp = wave >> 2;
+    if (tid < 2 * C) *reinterpret_cast<float*>(lds + BIAS_OFF + tid * 4) = tid < C ? p.ba[tid] : p.bb[tid - C];
+    *reinterpret_cast<float*>(lds + BIAS_OFF + 2 * C * 4 + tid * 4) = p.bc[tid];             // 512 threads, 512 channels; visible after phase A's barriers
+    uint4 wn[4];                                     // first weight fragments of the next phase, requested one phase early
+    auto stamp = [&](int k) {
+        if (p.ts && tid == 0) p.ts[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+
+    // ================================================================ phase A: t1 = relu(Wa x + ba) on the halo, K = CIN
+    {
+        constexpr int NK = CIN / 64;
+        f32x16 acc[TPG];
+#pragma unroll
+        for (int i = 0; i < TPG; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const int np = (NGA - wave + 7) / 8;         // row groups of this wave: wave, wave + 8, wave + 16 (< 23)
+        const bf16_t* xsrc[3];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int g = wave + 8 * i;
+            const int hr = g * 8 + rsub;
+            const int hy = hr / HTX, hx = hr - hy * HTX;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NGA && hr < HR && y >= 0 && y < HW && x >= 0 && x < HW;
+            xsrc[i] = ok ? X + ((size_t)y * HW + x) * CIN + (cpos ^ ((hr >> 1) & 7)) * 8 : zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        auto issue_x = [&](int kt) {
+            unsigned char* sb = lds + (kt % 3) * SLOT;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int g = wave + 8 * i;
+                if (g < NGA) dma16(xsrc[i] + (((okmask >> i) & 1u) ? kt * 64 : 0), sb + g * 1024);
+            }
+        };
+        u32x4 wq[2][4];
+        auto load_w = [&](int kt, int set) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, ctw, CIN / 16, kt * 4 + ks, lane)) : "memory");
+        };
+        const int pt0 = grp * TPG;
+        load_w(0, 0);
+        issue_x(0);
+        issue_x(1);
+        for (int kt2 = 0; kt2 < NK; kt2 += 2)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int kt = kt2 + par;
+            if (kt + 1 < NK) wait_vmcnt_n(np); else wait_vmcnt<0>();   // only X(kt+1) is younger than W(kt)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
+            if (kt + 2 < NK) issue_x(kt + 2);        // slot (kt+2) % 3 == slot of tile kt-1: done for every wave
+            const unsigned xb = lds_base + (kt % 3) * SLOT;
+            u32x4 pf[TPG];
+            const unsigned xrow = xb + (pt0 * 32 + lrow) * ROWB;
+            auto rd = [&](int ks, int half) {
+                const unsigned a = xrow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); }
+                else pf[2] = lds_read_b128_o<8192>(a);
+            };
+            rd(0, 0);
+            rd(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 w = wq[par][ks];
+                lgkm_wait<1>();                      // half 0 landed (half 1 may be in flight)
+                acc[0] = mfma_bf16(w, pf[0], acc[0]);
+                acc[1] = mfma_bf16(w, pf[1], acc[1]);
+                if (ks < 3) rd(ks + 1, 0);
+                if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
+                acc[2] = mfma_bf16(w, pf[2], acc[2]);
+                if (ks < 3) rd(ks + 1, 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // the ring is dead: its space becomes t1
+        asm volatile("" ::: "memory");
+        stamp(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, 9 * C / 16, ks, lane);
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (ctw * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+        for (int i = 0; i < TPG; ++i) {
+            const int hr = (pt0 + i) * 32 + lrow;
+            const int hy = hr / HTX, hx = hr - hy * HTX;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool in = y >= 0 && y < HW && x >= 0 && x < HW;
+            if (hr < HR) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk;
+                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
+                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                }
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(2);
+    }
+
+    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x NSL slices
+    {
+        constexpr int KSB = 9 * C / 16, NSTEP = 9 * NSL;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int hb[2];                                   // halo row of this lane's output pixel at tap (0,0)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = (grp * 2 + i) * 32 + lrow;
+            hb[i] = (q >> 4) * HTX + (q & 15);
+        }
+#pragma unroll 1
+        for (int step = 0; step < NSTEP; ++step) {   // step = tap * NSL + slice
+            const int tap = step / NSL, sl = step - tap * NSL;
+            u32x4 wc[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+            if (step + 1 < NSTEP) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
+            }
+            unsigned rowa[2], rkey[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int hr = hb[i] + (tap / 3) * HTX + (tap % 3);
+                rowa[i] = lds_base + sl * T1S + hr * ROWB;
+                rkey[i] = (hr >> 1) & 7;
+            }
+            u32x4 pf[2];
+            auto rd = [&](int ks, int half) {
+                const int ch = 2 * ks + lhalf;
+                pf[half] = lds_read_b128(rowa[half] + ((ch ^ rkey[half]) << 4));
+            };
+            rd(0, 0);
+            rd(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                lgkm_wait<1>();
+                acc[0] = mfma_bf16(wc[ks], pf[0], acc[0]);
+                if (ks < 3) rd(ks + 1, 0);
+                if (ks < 3) lgkm_wait<1>(); else lgkm_wait<0>();
+                acc[1] = mfma_bf16(wc[ks], pf[1], acc[1]);
+                if (ks < 3) rd(ks + 1, 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
+        asm volatile("" ::: "memory");
+        stamp(3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, C / 16, ks, lane);
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (C + ctw * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int px = (grp * 2 + i) * 32 + lrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
+                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
+                lds_write_b64(lds_base + (ctw >> 1) * T2S + px * ROWB + ((((ctw & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stamp(4);
+    }
+
+    // ================================================================ phase C: y = relu(Wc t2 + bc + x), 2 chunks of 8 channel tiles
+    {
+        constexpr int KSC = C / 16, NCH = (CIN / 32) / 8, NSTEP = NCH * NSL;
+        f32x16 acc[4];
+        float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
+        const int u = lane & 3, prr = lane >> 2;
+        auto pix = [&](int q) { return (size_t)((y0 + (q >> 4)) * HW + x0 + (q & 15)) * CIN; };   // tile pixel q -> frame offset
+#pragma unroll 1
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const int ct = chunk * 8 + wave;
+            const size_t cofs = (size_t)ct * 32 + 8 * u;
+            uint4 rr[2];                             // residual of the first pixel tile: in flight under the chunk's MFMAs
+#pragma unroll
+            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
+            {
+                float4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (2 * C + ct * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+                    }
+            }
+#pragma unroll 1
+            for (int sl = 0; sl < NSL; ++sl) {
+                u32x4 wc[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+                const int nxt = chunk * NSL + sl + 1;
+                if (nxt < NSTEP) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, (nxt / NSL) * 8 + wave, KSC, (nxt % NSL) * 4 + ks, lane);
+                }
+                const unsigned tb = lds_base + sl * T2S;
+                u32x4 pf[4];
+                const unsigned trow = tb + lrow * ROWB;
+                auto rd = [&](int ks, int half) {
+                    const unsigned a = trow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                    if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); }
+                    else { pf[2] = lds_read_b128_o<8192>(a); pf[3] = lds_read_b128_o<12288>(a); }
+                };
+                rd(0, 0);
+                rd(0, 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    lgkm_wait<2>();
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 0);
+                    if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
+#pragma unroll
+                    for (int i = 2; i < 4; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 1);
+                }
+            }
+            if (chunk == NCH - 1) stamp(5);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int slot = (2 * g + lhalf) ^ (lrow & 7);
+                    *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                }
+                uint4 rn[2];
+                if (i < 3) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) rn[it] = *reinterpret_cast<const uint4*>(X + pix((i + 1) * 32 + it * 16 + prr) + cofs);
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int pr = it * 16 + prr;
+                    const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u) ^ (pr & 7)) << 2));
+                    const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u + 1) ^ (pr & 7)) << 2));
+                    const unsigned w4[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                    *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+                if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
+            }
+        }
+        stamp(6);
+    }
+}
+
 // ---------------------------------------------------------------- res2, small tile: two workgroups per CU
 // The 16x16-tile kernel above runs ONE workgroup per CU, so its memory phases (x halo in, residual in / y out) and its
 // MFMA phases alternate instead of overlapping: 37k cycles per tile against ~10k of MFMA issue and ~18k of HBM time.
@@ -1428,7 +1735,8 @@ void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     ConvArgs d{};
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.ds ? nullptr : a.x;
     void* tok = prof_begin(d, 2, st);
-    if (a.Cmid == 128) hipLaunchKernelGGL((bneck_halo_kernel<128>), dim3(a.B * 4), dim3(512), 0, st, a);
+    if (a.Cmid == 128 && tune_get("HALO128S", 0)) hipLaunchKernelGGL(bneck_halo128s_kernel, dim3(a.B * 8), dim3(512), 0, st, a);
+    else if (a.Cmid == 128) hipLaunchKernelGGL((bneck_halo_kernel<128>), dim3(a.B * 4), dim3(512), 0, st, a);
     else if (a.ds && a.t1out && a.nd == 64) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 64>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.ds) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 0>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64 && a.t1in && a.t1out && a.nd == 64) hipLaunchKernelGGL((bneck_halo64s_kernel<false, true, 64>), dim3(a.B * 32), dim3(512), 0, st, a);

@@ -482,3 +482,23 @@ def test_roi_crop_with_boxes_over_every_frame_border(dev):
         L.check(lib.ivosw_roi_sample(L.dptr(d_tf), L.dptr(d_tp), L.dptr(d_box), B, H, W, L.BF16, L.dptr(r16), L.stream_ptr(dev)), "roi_sample")
         # the same values rounded to bf16 (the two template instances may contract fp32 operations differently: one bf16 ulp)
         np.testing.assert_allclose(r16.float().cpu().numpy(), got, rtol=2.0 ** -7, atol=1e-3)
+
+
+def test_res3_small_tile_kernel_is_bit_identical(dev, net16):
+    """res3's identity blocks on 8 x 16-pixel tiles with two workgroups per CU (bneck_halo128s_kernel, tunable HALO128S=1;
+    measured slower, off by default) against the 16 x 16-tile kernel (HALO128S=0): the same MFMAs in the same K order per output pixel, so the res3
+    output and the scores must agree bit for bit - full, odd and chunked batches, frames at the batch edge."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge, chunk in ((8, True, 0), (3, False, 0), (5, False, 2)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
+        got = {}
+        try:
+            for mode in (1, 0):
+                lib.ivosw_tune_set(b"HALO128S", mode)
+                got[mode] = [net.forward_tap(ttf, ttp, "res3")[1].clone(), net(ttf, ttp).clone()]
+        finally:
+            lib.ivosw_tune_set(b"HALO128S", 0)
+        for a, b, nm in zip(got[1], got[0], ("res3", "scores")):
+            assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
