@@ -345,7 +345,7 @@ def bench_assess(args, rank, world, dev, dist):
 
 
 def net_chunk(args):
-    return args.chunk or (256 if args.precision == "bf16" else 16)
+    return args.chunk or (256 if args.precision == "bf16" else 64)      # the library defaults (assess.hip: default_chunk)
 
 
 def bench_fp32(args, dev, tf, tp, scores16, pick):
