@@ -33,18 +33,36 @@ __global__ __launch_bounds__(256) void bbox_scan_kernel(const float* __restrict_
     const size_t end = min(plane, beg + (size_t)chunk);
     int ymin = INT_MAX, ymax = -1, xmin = INT_MAX, xmax = -1;
     if (vec_ok) {  // plane % 4 == 0, chunk % 4 == 0, base 16-B aligned: 16 B per lane, fully coalesced
-        for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += 256 * 4) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
-            const float e[4] = {v.x, v.y, v.z, v.w};
-            int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        // four 16-byte loads per lane in flight, (y, x) carried incrementally (no 64-bit division per load), and the per-element
+        // work only for a float4 that holds a foreground pixel at all
+        size_t i = beg + (size_t)threadIdx.x * 4;
+        int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        const int sy = 1024 / W, sx = 1024 % W;                      // one block stride = 1024 elements
+        auto visit = [&](const float4& v, int yy, int xx) {
+            if (fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) > 0.5f) {   // tm = (tp > 0.5); mask >= 0.49 on {0,1} is the same set (assessment.py:165,115)
+                const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (e[j] > 0.5f) {  // tm = (tp > 0.5); mask >= 0.49 on {0,1} is the same set (assessment.py:165,115)
-                    ymin = min(ymin, y); ymax = max(ymax, y);
-                    xmin = min(xmin, x); xmax = max(xmax, x);
+                for (int j = 0; j < 4; ++j) {
+                    if (e[j] > 0.5f) {
+                        ymin = min(ymin, yy); ymax = max(ymax, yy);
+                        xmin = min(xmin, xx); xmax = max(xmax, xx);
+                    }
+                    if (++xx == W) { xx = 0; ++yy; }
                 }
-                if (++x == W) { x = 0; ++y; }
             }
+        };
+        auto step = [&](int& yy, int& xx) { yy += sy; xx += sx; if (xx >= W) { xx -= W; ++yy; } };
+        for (; i + 3 * 1024 < end; i += 4 * 1024) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p + i), v1 = *reinterpret_cast<const float4*>(p + i + 1024);
+            const float4 v2 = *reinterpret_cast<const float4*>(p + i + 2048), v3 = *reinterpret_cast<const float4*>(p + i + 3072);
+            visit(v0, y, x); step(y, x);
+            visit(v1, y, x); step(y, x);
+            visit(v2, y, x); step(y, x);
+            visit(v3, y, x); step(y, x);
+        }
+        for (; i < end; i += 1024) {
+            visit(*reinterpret_cast<const float4*>(p + i), y, x);
+            step(y, x);
         }
     } else {
         for (size_t i = beg + threadIdx.x; i < end; i += 256) {
