@@ -397,7 +397,7 @@ def test_conv1_forwarding_through_res2_is_bit_identical(dev, net16):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
 
-def test_two_stream_split_is_invisible_in_the_scores(dev, net16):
+def test_two_stream_split_is_invisible_in_the_scores(dev, net16, net32):
     """bf16, default chunk, B >= 128: ivosw_assess_forward runs the batch as two halves on two streams (tunable STREAMS2=1, default;
     the second half on the library's side stream with its own workspace).  A frame's score does not depend on the batch it travels
     in, so the scores must equal the one-stream run bit for bit — for an even split (256), an uneven one (136 -> 72 + 64) and
@@ -406,7 +406,7 @@ def test_two_stream_split_is_invisible_in_the_scores(dev, net16):
     from ivos_w_amd import _lib as L
     lib = L.lib()
     assert lib.ivosw_assess_split(L.BF16, 256, 0) == 1 and lib.ivosw_assess_split(L.BF16, 64, 0) == 0
-    assert lib.ivosw_assess_split(L.F32, 256, 0) == 0 and lib.ivosw_assess_split(L.BF16, 256, 64) == 0
+    assert lib.ivosw_assess_split(L.F32, 256, 0) == 1 and lib.ivosw_assess_split(L.BF16, 256, 64) == 0      # fp32 splits too (STREAMS2_F32)
     _, _, tf8, tp8 = inputs(dev, 8, True)
     for B in (256, 136):
         ttf = tf8.repeat((B + 7) // 8, 1, 1, 1)[:B].contiguous()
@@ -424,6 +424,17 @@ def test_two_stream_split_is_invisible_in_the_scores(dev, net16):
         for a, b in got[1]:
             assert torch.equal(a, got[0][0][0]) and torch.equal(b, got[0][0][1]), B
             assert torch.equal(a, b.flip(0)), B
+    # the fp32 parity mode takes the same split: bit-equal scores with and without it
+    ttf = tf8.repeat(17, 1, 1, 1)[:136].contiguous()
+    ttp = torch.roll(tp8.repeat(17, 1, 1)[:136], shifts=3, dims=0).contiguous()
+    try:
+        f = {}
+        for mode in (1, 0):
+            lib.ivosw_tune_set(b"STREAMS2", mode)
+            f[mode] = net32(ttf, ttp).clone()
+    finally:
+        lib.ivosw_tune_set(b"STREAMS2", 1)
+    assert torch.equal(f[1], f[0])
     # ... and of the batch SIZE, multiples of 4 or not (res5's patch-resident 3x3 packs four 8x8 frames per tile: with B % 4 != 0
     # the whole launch used to fall back to the per-tap kernel, another summation order): every frame of a 150- / 67-frame
     # batch scores what it scores in a launch of its 8 neighbours
