@@ -152,7 +152,7 @@ int ivosw_assess_pack(void* packed, int dtype, const void* const* tensors, int n
  * 4..7 res2..res5 outputs, NHWC in `dtype`; 8 pooled [.,2048] fp32.  Only with B <= chunk.        */
 size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk);
 /* 1 when ivosw_assess_forward(dtype, B, chunk) runs the batch as two independent halves on two streams (bf16, default chunk,
- * B >= 128, tunables STREAMS2 / STREAMS2_MIN; the workspace query above already covers both halves), else 0.  Scores do not depend on it. */
+ * B >= 64, tunables STREAMS2 / STREAMS2_MIN; the workspace query above already covers both halves), else 0.  Scores do not depend on it. */
 int ivosw_assess_split(int dtype, int B, int chunk);
 int ivosw_assess_forward(const void* packed, int dtype, const float* tf, const float* tp,
                          int B, int H, int W, float* scores, void* ws, size_t ws_bytes, int chunk,
