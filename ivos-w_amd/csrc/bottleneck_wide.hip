@@ -1038,6 +1038,301 @@ __global__ __launch_bounds__(512, 4) void bneck_halo128s_kernel(BneckWideArgs p)
     }
 }
 
+// ---------------------------------------------------------------- res4, half-frame tile: small batches
+// The frame kernel above gives a frame to ONE workgroup, so a launch of B frames occupies B of the 256 CUs: an evaluation-size
+// batch (a sequence's 50 - 130 (frame, object) units, or one half of it after the two-stream split) leaves most of the chip idle for
+// the five res4 identity blocks.  Here a workgroup owns an 8 x 16-pixel HALF frame (10 x 16 halo = 180 rows with the two
+// out-of-frame columns zero, 6 pixel tiles): 2 B workgroups per launch.  Dataflow of bneck_halo_kernel with C = 256 (wave =
+// channel tile in phases A and B, = output-channel tile of a chunk in phase C); per pixel the arithmetic and its order are those
+// of the frame kernel, so a frame's result does not depend on which of the two ran it (bit-identical: tests).
+// LDS: [0, 73728) x ring (3 x 24 KB) -> t1 (4 slices x 192 rows) [0, 98304) -> t2 (4 x 128 rows) [0, 65536) | staging [65536, 98304);
+//      [98304, 104448) biases.
+__global__ __launch_bounds__(512) void bneck_half16_kernel(BneckWideArgs p) {
+    constexpr int C = 256, CIN = 1024, HW = 16, BTY = 8, HTX = 18, HR = 180, MH = 192, NGA = 23;
+    constexpr int TPF = HW / BTY;                    // 2 tiles per frame
+    constexpr int NSL = 4;
+    constexpr int SLOT = 24576;
+    constexpr int T1S = MH * ROWB, T2S = 128 * ROWB;
+    constexpr int STG_OFF = NSL * T2S, BIAS_OFF = NSL * T1S, LDS_BYTES = BIAS_OFF + 6 * C * 4;       // 65536, 98304, 104448
+    static_assert(3 * SLOT <= NSL * T1S && STG_OFF + 8 * 4096 <= BIAS_OFF && LDS_BYTES <= WIDE_LDS, "LDS map");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = L / TPF, tl = L - b * TPF;
+    const int y0 = tl * BTY, x0 = 0;
+    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * HW * HW * CIN;
+    bf16_t* Y = static_cast<bf16_t*>(p.y) + (size_t)b * HW * HW * CIN;
+    const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
+    const int ctw = wave;
+    *reinterpret_cast<float*>(lds + BIAS_OFF + tid * 4) = tid < C ? p.ba[tid] : p.bb[tid - C];
+    *reinterpret_cast<float*>(lds + BIAS_OFF + 2 * C * 4 + tid * 4) = p.bc[tid];                     // visible after phase A's barriers
+    *reinterpret_cast<float*>(lds + BIAS_OFF + 2 * C * 4 + (tid + 512) * 4) = p.bc[tid + 512];
+    uint4 wn[4];                                     // first weight fragments of the next phase, requested one phase early
+
+    // ================================================================ phase A: t1 = relu(Wa x + ba) on the halo, K = CIN
+    {
+        constexpr int NK = CIN / 64;
+        f32x16 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const int np = (NGA - wave + 7) / 8;         // row groups of this wave: wave, wave + 8, wave + 16 (< 23)
+        const bf16_t* xsrc[3];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int g = wave + 8 * i;
+            const int hr = g * 8 + rsub;
+            const int hy = hr / HTX, hx = hr - hy * HTX;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NGA && hr < HR && y >= 0 && y < HW && x >= 0 && x < HW;
+            xsrc[i] = ok ? X + ((size_t)y * HW + x) * CIN + (cpos ^ ((hr >> 1) & 7)) * 8 : zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        auto issue_x = [&](int kt) {
+            unsigned char* sb = lds + (kt % 3) * SLOT;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int g = wave + 8 * i;
+                if (g < NGA) dma16(xsrc[i] + (((okmask >> i) & 1u) ? kt * 64 : 0), sb + g * 1024);
+            }
+        };
+        u32x4 wq[2][4];
+        auto load_w = [&](int kt, int set) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, ctw, CIN / 16, kt * 4 + ks, lane)) : "memory");
+        };
+        load_w(0, 0);
+        issue_x(0);
+        issue_x(1);
+        for (int kt2 = 0; kt2 < NK; kt2 += 2)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int kt = kt2 + par;
+            if (kt + 1 < NK) wait_vmcnt_n(np); else wait_vmcnt<0>();   // only X(kt+1) is younger than W(kt)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < NK) load_w(kt + 1, par ^ 1);
+            if (kt + 2 < NK) issue_x(kt + 2);        // slot (kt+2) % 3 == slot of tile kt-1: done for every wave
+            const unsigned xb = lds_base + (kt % 3) * SLOT;
+            u32x4 pf[6];
+            const unsigned xrow = xb + lrow * ROWB;
+            auto rd = [&](int ks, int half) {
+                const unsigned a = xrow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); pf[2] = lds_read_b128_o<8192>(a); }
+                else { pf[3] = lds_read_b128_o<12288>(a); pf[4] = lds_read_b128_o<16384>(a); pf[5] = lds_read_b128_o<20480>(a); }
+            };
+            rd(0, 0);
+            rd(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const u32x4 w = wq[par][ks];
+                lgkm_wait<3>();                      // half 0 landed (half 1 may be in flight)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = mfma_bf16(w, pf[t], acc[t]);
+                if (ks < 3) rd(ks + 1, 0);
+                if (ks < 3) lgkm_wait<3>(); else lgkm_wait<0>();
+#pragma unroll
+                for (int t = 3; t < 6; ++t) acc[t] = mfma_bf16(w, pf[t], acc[t]);
+                if (ks < 3) rd(ks + 1, 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // the ring is dead: its space becomes t1
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, 9 * C / 16, ks, lane);
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (ctw * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int hr = i * 32 + lrow;
+            const int hy = hr / HTX, hx = hr - hy * HTX;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool in = y >= 0 && y < HW && x >= 0 && x < HW;
+            if (hr < HR) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    u32x2 pk;
+                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
+                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                }
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ================================================================ phase B: t2 = relu(Wb (*) t1 + bb), 9 taps x NSL slices
+    {
+        constexpr int KSB = 9 * C / 16, NSTEP = 9 * NSL;
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        int hb[4];                                   // halo row of this lane's output pixel at tap (0,0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * 32 + lrow;
+            hb[i] = (q >> 4) * HTX + (q & 15);
+        }
+#pragma unroll 1
+        for (int step = 0; step < NSTEP; ++step) {   // step = tap * NSL + slice
+            const int tap = step / NSL, sl = step - tap * NSL;
+            u32x4 wc[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+            if (step + 1 < NSTEP) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
+            }
+            unsigned rowa[4], rkey[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int hr = hb[i] + (tap / 3) * HTX + (tap % 3);
+                rowa[i] = lds_base + sl * T1S + hr * ROWB;
+                rkey[i] = (hr >> 1) & 7;
+            }
+            u32x4 pf[4];
+            auto rd = [&](int ks, int half) {
+                const int ch = 2 * ks + lhalf;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(rowa[half * 2 + i] + ((ch ^ rkey[half * 2 + i]) << 4));
+            };
+            rd(0, 0);
+            rd(0, 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                lgkm_wait<2>();
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                if (ks < 3) rd(ks + 1, 0);
+                if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
+#pragma unroll
+                for (int i = 2; i < 4; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                if (ks < 3) rd(ks + 1, 1);
+            }
+        }
+        __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, wave, C / 16, ks, lane);
+        float4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (C + ctw * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = i * 32 + lrow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x2 pk;
+                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
+                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
+                lds_write_b64(lds_base + (ctw >> 1) * T2S + px * ROWB + ((((ctw & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
+            }
+        }
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ================================================================ phase C: y = relu(Wc t2 + bc + x), 4 chunks of 8 channel tiles
+    {
+        constexpr int KSC = C / 16, NCH = (CIN / 32) / 8, NSTEP = NCH * NSL;
+        f32x16 acc[4];
+        float* stg = reinterpret_cast<float*>(lds + STG_OFF + wave * 4096);
+        const int u = lane & 3, prr = lane >> 2;
+        auto pix = [&](int q) { return (size_t)((y0 + (q >> 4)) * HW + x0 + (q & 15)) * CIN; };   // tile pixel q -> frame offset
+#pragma unroll 1
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const int ct = chunk * 8 + wave;
+            const size_t cofs = (size_t)ct * 32 + 8 * u;
+            uint4 rr[2];                             // residual of the first pixel tile: in flight under the chunk's MFMAs
+#pragma unroll
+            for (int it = 0; it < 2; ++it) rr[it] = *reinterpret_cast<const uint4*>(X + pix(it * 16 + prr) + cofs);
+            {
+                float4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (2 * C + ct * 32 + 8 * g + 4 * lhalf) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        acc[i][4 * g] = bq[g].x; acc[i][4 * g + 1] = bq[g].y; acc[i][4 * g + 2] = bq[g].z; acc[i][4 * g + 3] = bq[g].w;
+                    }
+            }
+#pragma unroll 1
+            for (int sl = 0; sl < NSL; ++sl) {
+                u32x4 wc[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+                const int nxt = chunk * NSL + sl + 1;
+                if (nxt < NSTEP) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fc, (nxt / NSL) * 8 + wave, KSC, (nxt % NSL) * 4 + ks, lane);
+                }
+                const unsigned tb = lds_base + sl * T2S;
+                u32x4 pf[4];
+                const unsigned trow = tb + lrow * ROWB;
+                auto rd = [&](int ks, int half) {
+                    const unsigned a = trow + (((2 * ks + lhalf) ^ ((lrow >> 1) & 7)) << 4);
+                    if (half == 0) { pf[0] = lds_read_b128_o<0>(a); pf[1] = lds_read_b128_o<4096>(a); }
+                    else { pf[2] = lds_read_b128_o<8192>(a); pf[3] = lds_read_b128_o<12288>(a); }
+                };
+                rd(0, 0);
+                rd(0, 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    lgkm_wait<2>();
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 0);
+                    if (ks < 3) lgkm_wait<2>(); else lgkm_wait<0>();
+#pragma unroll
+                    for (int i = 2; i < 4; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
+                    if (ks < 3) rd(ks + 1, 1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int slot = (2 * g + lhalf) ^ (lrow & 7);
+                    *reinterpret_cast<float4*>(stg + lrow * 32 + slot * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+                }
+                uint4 rn[2];
+                if (i < 3) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) rn[it] = *reinterpret_cast<const uint4*>(X + pix((i + 1) * 32 + it * 16 + prr) + cofs);
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int pr = it * 16 + prr;
+                    const float4 v0 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u) ^ (pr & 7)) << 2));
+                    const float4 v1 = *reinterpret_cast<const float4*>(stg + pr * 32 + (((2 * u + 1) ^ (pr & 7)) << 2));
+                    const unsigned w4[4] = {rr[it].x, rr[it].y, rr[it].z, rr[it].w};
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                    *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+                if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- res2, small tile: two workgroups per CU
 // The 16x16-tile kernel above runs ONE workgroup per CU, so its memory phases (x halo in, residual in / y out) and its
 // MFMA phases alternate instead of overlapping: 37k cycles per tile against ~10k of MFMA issue and ~18k of HBM time.
@@ -1729,6 +2024,14 @@ bool bneck_wide_fusable(const BneckWideArgs& a) {
     return a.Cmid == 256 && a.H == 16;
 }
 
+// res4 identity blocks of a small launch (<= HALF16_MAX frames, default 96) run on half-frame tiles, block by block (a tile's halo
+// comes from the other half of the frame: no chaining inside one launch).  Frames/s with and without, by batch (two streams from
+// 64 units, so a launch carries half the batch; tools/half16_sweep.sh): B = 32 + 14 %, 64 + 11 %, 100 + 9 %, 128 + 5 %, 160 + 3 %,
+// 200 (100 frames per launch) + 0.3 %, 256 (128 per launch) - 2.7 % - the chained stage kernel wins once every CU has a frame.
+static bool bneck_half16_wanted(const BneckWideArgs& a) {
+    return !a.ds && a.Cmid == 256 && a.H == 16 && a.W == 16 && a.zeros && a.B <= tune_get("HALF16_MAX", 96);
+}
+
 void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     BneckWideArgs a = a_in;
     a.debug = tune_get("BDBG", 0);
@@ -1744,13 +2047,14 @@ void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     else if (a.Cmid == 64 && a.t1in && a.t1out && a.nd == 128) hipLaunchKernelGGL((bneck_halo64s_kernel<false, true, 128>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64 && tune_get("HALO64S", 1)) hipLaunchKernelGGL((bneck_halo64s_kernel<false, false, 0>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.Cmid == 64) hipLaunchKernelGGL((bneck_halo_kernel<64>), dim3(a.B * 16), dim3(512), 0, st, a);
+    else if (a.Cmid == 256 && bneck_half16_wanted(a)) hipLaunchKernelGGL(bneck_half16_kernel, dim3(a.B * 2), dim3(512), 0, st, a);
     else if (a.Cmid == 256) hipLaunchKernelGGL((bneck_wide_kernel<256, 16, 1>), dim3(a.B), dim3(512), 0, st, a);
     else if (tune_get("FUSE_WIDE5", 0) == 2) hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 1>), dim3(a.B), dim3(512), 0, st, a);   // one frame per workgroup
     else hipLaunchKernelGGL((bneck_wide_kernel<512, 8, 2>), dim3(a.B / 2), dim3(512), 0, st, a);
     prof_end(tok, st);
 }
 
-bool bneck_stage_fusable(const BneckWideArgs& a) { return !a.ds && a.Cmid == 256 && a.H == 16 && a.W == 16 && tune_get("STAGE_RUN", 1) != 0; }
+bool bneck_stage_fusable(const BneckWideArgs& a) { return !a.ds && a.Cmid == 256 && a.H == 16 && a.W == 16 && tune_get("STAGE_RUN", 1) != 0 && !bneck_half16_wanted(a); }
 
 void launch_bneck_wide_stage(const BneckStageArgs& s_in, hipStream_t st) {
     BneckStageArgs s = s_in;

@@ -513,3 +513,23 @@ def test_res3_small_tile_kernel_is_bit_identical(dev, net16):
             lib.ivosw_tune_set(b"HALO128S", 0)
         for a, b, nm in zip(got[1], got[0], ("res3", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
+
+
+def test_res4_half_frame_kernel_is_bit_identical(dev, net16):
+    """Small launches (<= HALF16_MAX = 96 frames) run res4's identity blocks on 8 x 16-pixel half frames (bneck_half16_kernel, two
+    workgroups per frame) instead of one frame per workgroup: the same MFMAs in the same K order per output pixel, so the res4
+    output and the scores agree bit for bit with HALF16_MAX=0 (frame / stage kernels) - full, odd and chunked batches."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge, chunk in ((8, True, 0), (3, False, 0), (5, False, 2)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
+        got = {}
+        try:
+            for mode in (96, 0):
+                lib.ivosw_tune_set(b"HALF16_MAX", mode)
+                got[mode] = [net.forward_tap(ttf, ttp, "res4")[1].clone(), net(ttf, ttp).clone()]
+        finally:
+            lib.ivosw_tune_set(b"HALF16_MAX", 96)
+        for a, b, nm in zip(got[96], got[0], ("res4", "scores")):
+            assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
