@@ -2029,7 +2029,11 @@ bool bneck_wide_fusable(const BneckWideArgs& a) {
 // 64 units, so a launch carries half the batch; tools/half16_sweep.sh): B = 32 + 14 %, 64 + 11 %, 100 + 9 %, 128 + 5 %, 160 + 3 %,
 // 200 (100 frames per launch) + 0.3 %, 256 (128 per launch) - 2.7 % - the chained stage kernel wins once every CU has a frame.
 static bool bneck_half16_wanted(const BneckWideArgs& a) {
-    return !a.ds && a.Cmid == 256 && a.H == 16 && a.W == 16 && a.zeros && a.B <= tune_get("HALF16_MAX", 96);
+    // ... and for launches just above half the chip (129 .. HALF16_HI = 160 frames, i.e. batches of 258 .. 320 in two halves): the two
+    // concurrent frame-per-workgroup launches would need a second, mostly empty round of workgroups (B = 272 + 7 %, 300 + 5 %,
+    // 340 + 2 %; from 384 the stage kernel wins again)
+    if (a.ds || a.Cmid != 256 || a.H != 16 || a.W != 16 || !a.zeros) return false;
+    return a.B <= tune_get("HALF16_MAX", 96) || (a.B > 128 && a.B <= tune_get("HALF16_HI", 160));
 }
 
 void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
