@@ -858,6 +858,13 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
                 }
             }
             const int lw = tune_get("LW", 8);
+            // small launches (an evaluation-size batch: fewer 256 x 128 tiles than SMALL_GRID workgroups): 128 x 128 tiles, two
+            // workgroups per CU - twice the workgroups; same K order per output element, so a frame's result does not depend on it
+            if (nk > tune_nk && grid < tune_get("SMALL_GRID", 128)) {
+                const int g2 = ((M + 127) / 128) * (a.Cout / 128);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 3>), dim3(g2), dim3(512), 0, st, a);
+                return;
+            }
 
             if (nk > tune_nk && use_ws && lw == 8) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 8>), dim3(grid), dim3(1024), 0, st, a);
             else if (nk > tune_nk && use_ws) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 4>), dim3(grid), dim3(768), 0, st, a);
