@@ -170,7 +170,7 @@ def check_scores(scores, tf, tp, precision, pick):
     return {"frames": len(pick), "worst_rel_err": float(f"{err:.3e}"), "tolerance": tol, "against": "oracle/assess_oracle.py (torch-CPU restatement of AssessNet.forward)"}
 
 
-def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=150):
+def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=75):
     """roofline.traffic measured in THIS run: the same forward (batch 256, bf16, default chunk) is re-run in two child processes
     under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only - no trace domains), after the
     timed region, and the per-kernel counters of the tower family are summed exactly as tools/pmc_summary.py does for the
