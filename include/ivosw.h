@@ -101,6 +101,14 @@ int ivosw_p2p_free(void* arena);
 int ivosw_p2p_error(const void* arena, int* error);
 int ivosw_p2p_allreduce(const float* grads, float* out, int n, int rank, int world, void* const* arenas, unsigned epoch,
                         int timeout_ms, ivosw_stream_t stream);
+/* ivosw_p2p_allreduce followed by ivosw_clamp_adam(grad_scale = 1/world) as TWO launches: push, then wait + rank-ordered sum + clamp
+ * + Adam (the reference's clamp / optim.Adam step, models/agent.py:157-160, on the gradient averaged over the ranks).  grads_out
+ * (NULL allowed, may alias grads) receives the summed gradient; `step` is the 1-based Adam step.  On a timeout nothing is updated
+ * and the arena's error word is set (ivosw_p2p_error).                                                                        */
+int ivosw_p2p_allreduce_clamp_adam(const float* grads, float* grads_out, int n, int rank, int world, void* const* arenas,
+                                   unsigned epoch, int timeout_ms, float* params, float* exp_avg, float* exp_avg_sq, int step,
+                                   float lr, float beta1, float beta2, float eps, float weight_decay, float clamp,
+                                   ivosw_stream_t stream);
 
 /* ------------------------------------------------------------------ replay gather (K11) ------- */
 /* Replaces DataLoader shuffle+collate of memory_pool.csv rows (datasets/agent_dataset.py:71-115,
@@ -248,6 +256,12 @@ int ivosw_bneck_probe(const void* x, void* y, const void* wa, const float* ba, c
 int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, const float* ba, const void* wb, const float* bb,
                            const void* wc, const float* bc, void* frag, int B, int H, int W, int Cin, int Cmid,
                            unsigned long long* ts, ivosw_stream_t stream);
+
+/* Tuning probe: ONE launch of the res2 stage kernel (the three bottlenecks of res2 + res3's forwarded conv1; reference
+ * models/assessment.py:58-59) on x [B,64,64,64] bf16 with the weights of a packed bf16 arena (ivosw_assess_pack); y [B,64,64,256]
+ * (y_s2 != 0: the even pixels, [B,32,32,256]), t1out [B,64,64,128]; ts [B*32][16] uint64 phase stamps or NULL.            */
+int ivosw_res2_stage_probe(const void* packed, const void* x, void* y, void* t1out, int B, int y_s2, unsigned long long* ts,
+                           ivosw_stream_t stream);
 
 #ifdef __cplusplus
 }

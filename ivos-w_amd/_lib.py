@@ -37,6 +37,7 @@ SIGNATURES = {
     "ivosw_p2p_free": (_i, [_p]),
     "ivosw_p2p_error": (_i, [_p, C.POINTER(_i)]),
     "ivosw_p2p_allreduce": (_i, [_p, _p, _i, _i, _i, C.POINTER(_p), C.c_uint, _i, _p]),
+    "ivosw_p2p_allreduce_clamp_adam": (_i, [_p, _p, _i, _i, _i, C.POINTER(_p), C.c_uint, _i, _p, _p, _p, _i] + [_f] * 6 + [_p]),
     "ivosw_replay_gather": (_i, [_p] * 8 + [_i, _i] + [_p] * 5 + [_p]),
     "ivosw_lstm_probe": (_i, [_p, _p]),
     "ivosw_replay_draw_state_bytes": (_sz, []),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "ivosw_ablation_build": (_i, []),
     "ivosw_bneck_probe": (_i, [_p] * 11 + [_i] * 5 + [_p, _p]),
     "ivosw_bneck_wide_probe": (_i, [_p] * 9 + [_i] * 5 + [_p, _p]),
+    "ivosw_res2_stage_probe": (_i, [_p] * 4 + [_i] * 2 + [_p, _p]),
 }
 
 _lib = None

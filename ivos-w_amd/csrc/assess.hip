@@ -98,6 +98,22 @@ static Plan make_plan(int dtype) {
     return P;
 }
 
+// weights of the res2 stage kernel (res2_stage.hip) out of the packed bf16 arena
+static Res2StageArgs res2_stage_args(const Plan& P, const char* base) {
+    Res2StageArgs q{};
+    q.zeros = base + P.zero_off;
+    for (int b = 0; b < 3; ++b) {
+        const BlockPlan& bp = P.blocks[b];
+        const BlockPlan& nx = P.blocks[b + 1];
+        q.fb[b] = base + bp.f2_off; q.bb[b] = reinterpret_cast<const float*>(base + P.convs[bp.c2].b_off);
+        q.fc[b] = base + (b == 0 ? bp.cat_fw_off : bp.f3_off);
+        q.bc[b] = reinterpret_cast<const float*>(base + (b == 0 ? bp.cat_b_off : P.convs[bp.c3].b_off));
+        q.fd[b] = base + (b == 2 ? nx.fwd1_off : nx.f1_off); q.bd[b] = reinterpret_cast<const float*>(base + P.convs[nx.c1].b_off);
+    }
+    q.fa0 = base + P.blocks[0].f1_off; q.ba0 = reinterpret_cast<const float*>(base + P.convs[P.blocks[0].c1].b_off);
+    return q;
+}
+
 static const Plan& plan_for(int dtype) {
     static const Plan pb = make_plan(IVOSW_BF16), pf = make_plan(IVOSW_F32);
     return dtype == IVOSW_BF16 ? pb : pf;
@@ -229,7 +245,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 extern "C" int ivosw_assess_split(int dtype, int B, int chunk) { return split_wanted(dtype, B, chunk, 0) ? 1 : 0; }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
-    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
+    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
 static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,
@@ -364,9 +380,21 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     // ... and res2's last block then writes its output at the even pixels only (compact [nb,32,32,256]): with conv1 forwarded, the
     // only reader left is res3's stride-2 downsample.  Off when an intermediate is tapped (the res2 tap wants the whole tensor).
     const bool ys2 = fwd2 && tap_stage == 0 && tune_get("FUSE_DS", 1) && tune_get("YS2", 1);
+    // ... or the whole of res2 in ONE launch (res2_stage.hip, tunable RES2_STAGE): a workgroup carries its 8 x 16 tile through the
+    // three blocks, y0 / y1 never reach HBM.  Same summation orders as the per-block kernels: bit-identical stage output.
+    const bool stage2 = fwd2 && tune_get("RES2_STAGE", 0);
     auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {
         const char* x = x_in;
         int hw = hw_in[s];
+        if (s == 0 && stage2) {
+            Res2StageArgs q = res2_stage_args(P, base);
+            q.x = x; q.y = out; q.t1out = bf.m1 + (size_t)foff * 64 * 64 * 128 * es;
+            q.B = nb; q.y_s2 = ys2 ? 1 : 0;
+            if (res2_stage_ok(q)) {
+                launch_res2_stage(q, st);
+                return;
+            }
+        }
         for (int b = 0; b < nblk[s]; ++b) {
             const BlockPlan& bp = P.blocks[first_blk[s] + b];
             const ConvPlan &c1 = P.convs[bp.c1], &c2 = P.convs[bp.c2], &c3 = P.convs[bp.c3];
@@ -520,4 +548,19 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                        reinterpret_cast<const float*>(base + P.fcb_off), scores + f3, tap_stage == 8 ? bf.pooled : nullptr, st);
         tap(8, bf.pooled, (size_t)n3 * 2048 * sizeof(float));
     }
+}
+
+// Tuning probe: one launch of the res2 stage kernel on x [B,64,64,64] bf16 with the weights of a packed bf16 arena; y [B,64,64,256]
+// (y_s2: [B,32,32,256]), t1out [B,64,64,128]; ts (may be NULL): [B*32][16] s_memtime stamps at the phase boundaries.
+extern "C" int ivosw_res2_stage_probe(const void* packed, const void* x, void* y, void* t1out, int B, int y_s2, unsigned long long* ts,
+                                      ivosw_stream_t stream) {
+    IVOSW_REQUIRE(packed && x && y && t1out && B > 0, "null pointer");
+    IVOSW_ON_DEVICE_OF(y);
+    Res2StageArgs q = res2_stage_args(plan_for(IVOSW_BF16), static_cast<const char*>(packed));
+    q.x = x; q.y = y; q.t1out = t1out; q.B = B; q.y_s2 = y_s2; q.ts = ts;
+    q.debug = tune_get("R2DBG", 0);
+    IVOSW_REQUIRE(res2_stage_ok(q), "the packed arena lacks the fragment-ordered res2 weights");
+    launch_res2_stage(q, as_stream(stream));
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
 }

@@ -74,6 +74,23 @@ struct BneckStageArgs {
     int stagger;         // experiment (tunable STAGGER, 0 = off): cycles by which every second workgroup OF EACH XCD starts late
     BneckWideArgs blk[6];
 };
+// the whole of res2 (three bottlenecks at 64 x 64 + res3's forwarded conv1) in ONE launch, bf16 (res2_stage.hip): a workgroup owns an
+// 8 x 16 output tile through all three blocks, y0 / y1 never leave the chip
+struct Res2StageArgs {
+    const void* x;                     // NHWC [B,64,64,64]: the pooled stem output
+    void* y;                           // y2: NHWC [B,64,64,256], or (y_s2) its even pixels, compactly [B,32,32,256]
+    void* t1out;                       // NHWC [B,64,64,128]: res3's first 1x1 (+ BN + ReLU) applied to y2
+    const void* fa0; const float* ba0; // block 0 conv1 [64][64] in fragment order (launch_fragpack)
+    const void* fb[3]; const float* bb[3];   // conv2 [64][9*64] of the three blocks
+    const void* fc[3]; const float* bc[3];   // conv3: block 0 = [conv3 | downsample] [256][128] with the bias sum; blocks 1, 2 = [256][64]
+    const void* fd[3]; const float* bd[3];   // the NEXT block's conv1 [64|64|128][256]: blocks 1, 2 of res2 and block 0 of res3
+    const void* zeros;                 // >= 256 B of device zeros
+    int B, y_s2;
+    unsigned long long* ts;            // optional [grid][16] s_memtime stamps at the phase boundaries (ivosw_res2_stage_probe)
+    int debug;                         // IVOSW_ABLATION builds only (tunable R2DBG): 1 no weight loads, 2 pixel fragments read once per phase, 4 no MFMAs
+};
+bool res2_stage_ok(const Res2StageArgs& a);
+void launch_res2_stage(const Res2StageArgs& a, hipStream_t st);
 bool bneck_stage_fusable(const BneckWideArgs& a);
 void launch_bneck_wide_stage(const BneckStageArgs& s, hipStream_t st);
 bool bneck_wide_fusable(const BneckWideArgs& a);

@@ -1,7 +1,7 @@
 // Fused clamp + Adam over the flat parameter arena (K9), hard target sync (K10), replay gather (K11).
 // Reference: models/agent.py:157-165 (clamp, optim.Adam(lr, weight_decay) step, target sync),
 // datasets/agent_dataset.py:71-115 + train_agent.py:177-182 (minibatch assembly).
-#include "common.h"
+#include "adam.h"
 
 namespace ivosw {
 
@@ -13,17 +13,10 @@ __global__ void clamp_adam_kernel(float* __restrict__ p, const float* __restrict
                                   float eps, float wd, float clampv, float gscale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float gi = g[i] * gscale;
-    gi = fminf(fmaxf(gi, -clampv), clampv);
-    const float pi = p[i];
-    gi = fmaf(wd, pi, gi);
     float mi = m[i], vi = v[i];
-    mi = fmaf(gi - mi, 1.0f - beta1, mi);
-    vi = fmaf(1.0f - beta2, gi * gi, vi * beta2);
+    p[i] = clamp_adam_elem(g[i], p[i], mi, vi, step_size, bc2_sqrt, beta1, beta2, eps, wd, clampv, gscale);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - step_size * (mi / denom);
 }
 
 __global__ void replay_gather_kernel(const float* __restrict__ old_iou, const float* __restrict__ new_iou,
@@ -128,18 +121,6 @@ __global__ void quality_state_kernel(const float* __restrict__ scores, int n_obj
 // Adam's step counter and bias corrections kept ON the device, so that a captured HIP graph of the DQN step replays
 // correctly: tick advances step, evaluates beta1^t / beta2^t in float64 and publishes step_size / sqrt(bc2).
 // Layout (32 bytes): the step counter is the int32 at byte 16; a caller resumes from host step k by writing k there.
-// beta^step by squaring: multiplications only, so the host (ivosw_clamp_adam) and the device (adam_tick_kernel) get the same
-// float64 bits — libm's pow and the device's differ in the last place now and then, which moved step_size by a float ulp
-__host__ __device__ inline double ipow(double b, int n) {
-    double r = 1.0;
-    while (n > 0) {
-        if (n & 1) r *= b;
-        b *= b;
-        n >>= 1;
-    }
-    return r;
-}
-
 struct AdamDevState {
     double b1t, b2t;
     int step;
@@ -161,12 +142,7 @@ __global__ __launch_bounds__(1024) void clamp_adam_dev_kernel(float* __restrict_
     const double b1t = ipow((double)beta1, step), b2t = ipow((double)beta2, step);
     const float step_size = (float)((double)lr / (1.0 - b1t)), bc2_sqrt = (float)sqrt(1.0 - b2t);
     auto upd = [&](float gi, float pi, float& mi, float& vi) {
-        gi = fminf(fmaxf(gi * gscale, -clampv), clampv);
-        gi = fmaf(wd, pi, gi);
-        mi = fmaf(gi - mi, 1.0f - beta1, mi);
-        vi = fmaf(1.0f - beta2, gi * gi, vi * beta2);
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        return pi - step_size * (mi / denom);
+        return clamp_adam_elem(gi, pi, mi, vi, step_size, bc2_sqrt, beta1, beta2, eps, wd, clampv, gscale);
     };
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (VEC) {      // 16 bytes per lane and array; the n % 4 tail elements go to the first threads

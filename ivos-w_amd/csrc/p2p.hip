@@ -20,7 +20,7 @@
 // rank falls back to RCCL unless all of them pass.
 #include <algorithm>
 
-#include "common.h"
+#include "adam.h"
 
 namespace ivosw {
 
@@ -98,9 +98,84 @@ __global__ __launch_bounds__(1024) void p2p_reduce_kernel(float* __restrict__ ou
     else { out[i4] = s.x; if (i4 + 1 < n) out[i4 + 1] = s.y; if (i4 + 2 < n) out[i4 + 2] = s.z; }
 }
 
+// The same wait + rank-ordered sum, with clamp + Adam applied to the sum as it is formed ("every GPU sums 8 slots
+// locally inside the clamp_adam kernel"): the summed gradient never makes a round trip through HBM and the data-parallel step
+// loses a launch.  gout (may be NULL) receives the summed, unscaled gradient.  On a timeout NOTHING is updated and the error word
+// is set: the host raises (ivos_w_amd.parallel), replicas cannot drift apart silently.
+__global__ __launch_bounds__(1024) void p2p_reduce_clamp_adam_kernel(float* __restrict__ gout, int n, int world, void* arena, unsigned epoch,
+                                                                     unsigned long long timeout_ticks, float* __restrict__ p,
+                                                                     float* __restrict__ m, float* __restrict__ v, float step_size,
+                                                                     float bc2_sqrt, float beta1, float beta2, float eps, float wd,
+                                                                     float clampv, float gscale) {
+    P2pHeader* h = static_cast<P2pHeader*>(arena);
+    const int parity = epoch & 1;
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&h->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+            if (wall_clock64() - t0 > timeout_ticks) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (bad) {
+        if (threadIdx.x == 0) atomicExch(&h->error, 1u);
+        return;
+    }
+    const int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    float4 s = *reinterpret_cast<const float4*>(p2p_slot(arena, world, n, parity, 0) + i4);
+    for (int r = 1; r < world; ++r) {
+        const float4 q = *reinterpret_cast<const float4*>(p2p_slot(arena, world, n, parity, r) + i4);
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i4 + j;
+        if (i < n) {
+            float mi = m[i], vi = v[i];
+            p[i] = clamp_adam_elem(sv[j], p[i], mi, vi, step_size, bc2_sqrt, beta1, beta2, eps, wd, clampv, gscale);
+            m[i] = mi;
+            v[i] = vi;
+            if (gout) gout[i] = sv[j];
+        }
+    }
+}
+
 }  // namespace ivosw
 
 using namespace ivosw;
+
+// ivosw_p2p_allreduce + ivosw_clamp_adam(..., grad_scale = 1/world) as TWO launches instead of three: push, then wait + sum + clamp +
+// Adam.  grads_out (may be NULL, may alias grads) receives the summed gradient.  `step` is the 1-based Adam step, as in ivosw_clamp_adam.
+extern "C" int ivosw_p2p_allreduce_clamp_adam(const float* grads, float* grads_out, int n, int rank, int world, void* const* arenas,
+                                              unsigned epoch, int timeout_ms, float* params, float* exp_avg, float* exp_avg_sq, int step,
+                                              float lr, float beta1, float beta2, float eps, float weight_decay, float clamp,
+                                              ivosw_stream_t stream) {
+    IVOSW_REQUIRE(grads && arenas && params && exp_avg && exp_avg_sq, "null pointer");
+    IVOSW_ON_DEVICE_OF(params);
+    IVOSW_REQUIRE(n > 0 && world > 0 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world && epoch > 0 && step >= 1, "bad rank / world / epoch / step");
+    IVOSW_REQUIRE((reinterpret_cast<uintptr_t>(grads) & 15) == 0, "the gradient buffer must be 16-byte aligned");
+    P2pPeers peers{};
+    for (int r = 0; r < world; ++r) {
+        IVOSW_REQUIRE(arenas[r], "null arena");
+        peers.arena[r] = arenas[r];
+    }
+    const double bc1 = 1.0 - ipow((double)beta1, step), bc2 = 1.0 - ipow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    hipStream_t st = as_stream(stream);
+    const int nblk = ((n + 3) / 4 + 1023) / 1024;
+    hipLaunchKernelGGL(p2p_push_kernel, dim3(nblk), dim3(1024), 0, st, grads, n, rank, world, peers, epoch);
+    hipLaunchKernelGGL(p2p_reduce_clamp_adam_kernel, dim3(nblk), dim3(1024), 0, st, grads_out, n, world, arenas[rank], epoch,
+                       (unsigned long long)std::max(1, timeout_ms) * 100000ull, params, exp_avg, exp_avg_sq, step_size, bc2_sqrt, beta1, beta2,
+                       eps, weight_decay, clamp, 1.0f / (float)world);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
 
 extern "C" size_t ivosw_p2p_arena_bytes(int world, size_t n) {
     if (world <= 0 || world > P2P_MAX_WORLD || n == 0) return 0;

@@ -397,6 +397,29 @@ def test_conv1_forwarding_through_res2_is_bit_identical(dev, net16):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
 
+def test_res2_stage_kernel_is_bit_identical_to_the_per_block_kernels(dev, net16):
+    """bf16 mode: the whole of res2 (three bottlenecks + res3's forwarded conv1) in ONE launch (res2_stage.hip, tunable
+    RES2_STAGE=1): a workgroup carries its 8 x 16 tile through the three blocks on shrinking halos, y0 / y1 never reach HBM and the
+    residuals stay in registers.  Same bf16 roundings of every intermediate and the same K order per output element as the
+    per-block kernels (RES2_STAGE=0) -> res2 (full tensor through the tap, even-pixel tensor through the scores), res3 and the
+    scores must not move by a bit: full batch with edge masks (boxes touching the frame border exercise the zero padding of every
+    halo ring), an odd batch, and a chunked batch (two res2 chunks feeding one res3 chunk)."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge, chunk in ((8, True, 0), (3, False, 0), (6, False, 2)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
+        got = {}
+        try:
+            for mode in (1, 0):
+                lib.ivosw_tune_set(b"RES2_STAGE", mode)
+                got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3")] + [net(ttf, ttp).clone()]
+        finally:
+            lib.ivosw_tune_set(b"RES2_STAGE", 0)      # the default (assess.hip)
+        for a, b, nm in zip(got[1], got[0], ("res2", "res3", "scores")):
+            assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
+
+
 def test_two_stream_split_is_invisible_in_the_scores(dev, net16, net32):
     """bf16, default chunk, B >= 64: ivosw_assess_forward runs the batch as two halves on two streams (tunable STREAMS2=1, default;
     the second half on the library's side stream with its own workspace).  A frame's score does not depend on the batch it travels
