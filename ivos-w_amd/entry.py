@@ -462,17 +462,41 @@ def run_train(cfg):
     cfg.phase = "train"
     if not torch.cuda.is_available():
         raise SystemExit("[ivos-w] the hot path needs an MI355X (no CPU fallback)")
-    device = torch.device(f"cuda:{cfg.gpu_id}")
+    # Data parallel (BASELINE configs[3]; the reference has none, models/agent.py:90-92 is commented out): launched under
+    # torch.distributed.run, every rank plays the SAME episodes (same seeds -> the same experience, the same replay pool, the same
+    # epsilon / target-sync coins) and the exchange happens in the update loop: the shuffled minibatches of an episode are dealt
+    # out to the ranks (parallel.RankBatchSampler), gradients are summed over the ranks and averaged inside clamp + Adam
+    # (Agent.apply_gradients).  Rank 0 alone writes agent.pt / memory_pool.csv / the summaries into the configured directories;
+    # the other ranks keep their (identical) working files under <save_result_dir>/rank<r>.
+    from . import parallel
+    rank, world = 0, 1
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rank, world, device = parallel.init()
+        if rank > 0:
+            sys.stdout = open(os.devnull, "w")
+    else:
+        device = torch.device(f"cuda:{cfg.gpu_id}")
     choose_backend("ATNet", cfg)                                       # the reference trains against ATNet
     cfg.data.subset = cfg.data.get("subset", "train")
     misc.set_random_seed(2019)
     davis = SyntheticDavis(cfg, device)
     vos = StandInVOS(device, seed=int(cfg.seed))
-    save_dir = cfg.agent.save_result_dir
-    p_reward, p_pre = os.path.join(save_dir, cfg.agent.reward_csv), os.path.join(save_dir, cfg.agent.pretrain_csv)
-    if not (os.path.exists(p_reward) and os.path.exists(p_pre)):
+    shared_dir = cfg.agent.save_result_dir
+    p_reward, p_pre = os.path.join(shared_dir, cfg.agent.reward_csv), os.path.join(shared_dir, cfg.agent.pretrain_csv)
+    if rank == 0 and not (os.path.exists(p_reward) and os.path.exists(p_pre)):
         n = bootstrap_synthetic_pool(cfg, davis, vos, device)
         print(f"[ivos-w] bootstrapped {p_reward} / {p_pre} from random-policy episodes ({n} transitions)")
+    if world > 1:
+        torch.distributed.barrier()
+        if rank > 0:
+            import shutil
+            cfg.agent.save_result_dir = os.path.join(shared_dir, f"rank{rank}")
+            os.makedirs(cfg.agent.save_result_dir, exist_ok=True)
+            for src in (p_reward, p_pre):
+                shutil.copy(src, cfg.agent.save_result_dir)
+            p_reward, p_pre = (os.path.join(cfg.agent.save_result_dir, os.path.basename(q)) for q in (p_reward, p_pre))
+    save_dir = cfg.agent.save_result_dir
+    misc.set_random_seed(2019)                                         # the bootstrap consumed rank 0's streams: re-align every rank
     agent = Agent(device=device, cfg=cfg)
     df = pd.read_csv(p_reward, index_col=0)
     agent.memory_pool.load_from_csv(p_pre, save_dir, cfg.agent.sample_th)
@@ -484,6 +508,10 @@ def run_train(cfg):
     def loader_for(seen):
         if (seen - 1) % 3 == 0 or "ds" not in cache:
             cache["ds"] = load_agent_dataset(cfg, agent.memory_pool.seq_list)
+        if world > 1:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item() & 0x7fffffff)      # the global stream is the same on every rank
+            return DataLoader(cache["ds"], num_workers=0,
+                              batch_sampler=parallel.RankBatchSampler(len(cache["ds"]), int(cfg.agent.train_batch_size), rank, world, seed))
         return DataLoader(cache["ds"], batch_size=int(cfg.agent.train_batch_size), shuffle=True, num_workers=0)
     history, seen_seq = [], {}
     for epoch in range(1, int(cfg.num_epochs) + 1):
@@ -491,7 +519,8 @@ def run_train(cfg):
         sess = SyntheticSession(davis, cfg.data.subset, cfg.davis_interactive.metric, cfg.davis_interactive.max_nb_interactions,
                                 save_dir, seed=epoch, rounds=3)
         out = _episode(cfg, davis, vos, sess, agent, device, df, loader_for, "ours", seen_seq)
-        misc.save_agent_checkpoint(agent.policy_net, ckpt_dir=cfg.ckpt_dir)
+        if rank == 0:
+            misc.save_agent_checkpoint(agent.policy_net, ckpt_dir=cfg.ckpt_dir)
         gs = sess.get_global_summary()
         curve = gs["curve"][cfg.davis_interactive.metric][:-1]
         auc = float(np.trapz(curve) / (len(curve) - 1))
@@ -499,8 +528,26 @@ def run_train(cfg):
                             reward_done=float(np.mean(out["rewards_done"])), updates=agent.optimizer.state["step"]))
         print(f"# epoch {epoch}: auc:{auc:.4f} final {cfg.davis_interactive.metric}: {history[-1]['final'] * 100:.2f} agent loss: "
               f"{history[-1]['agent_loss']:.4f} reward_done: {history[-1]['reward_done']:.3f} updates: {history[-1]['updates']}")
-    with open(os.path.join(save_dir, "train_summary.json"), "w") as fp:
-        json.dump(history, fp)
+    if world > 1:
+        # replicas must be bit-identical: compare an exact integer checksum of the parameter bits on every rank
+        bits = agent.policy_net.flat.detach().view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=bits.device) % 1009 + 1)).sum()])
+        if torch.distributed.get_backend() == "gloo":
+            chk = chk.cpu()
+        got = [torch.empty_like(chk) for _ in range(world)]
+        torch.distributed.all_gather(got, chk)
+        same = all(bool(torch.equal(g, got[0])) for g in got)
+        for h in history:
+            h.update(world=world, replicas_identical=same, collective=parallel.collective_path(agent.policy_net.flat_grad))
+        for v in list(parallel._P2P.values()):
+            if v is not None:
+                v.close()
+        parallel._P2P.clear()
+        if not same:
+            raise SystemExit(f"[ivos-w] rank {rank}: the data-parallel replicas diverged (parameter checksums differ)")
+    if rank == 0:
+        with open(os.path.join(save_dir, "train_summary.json"), "w") as fp:
+            json.dump(history, fp)
     return history
 
 

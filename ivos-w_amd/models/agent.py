@@ -227,19 +227,24 @@ class Agent(nn.Module):
             print("no input")
             return
         loss = self.loss_and_grads(sample)
-        dist, world = self._world()
-        if world > 1:
-            # synchronous data parallel: sum over ranks (RCCL over xGMI), average inside the Adam kernel;
-            # the clamp therefore sees the averaged gradient, as a single large batch would
-            from .. import parallel
-            self.optimizer.grad_scale = parallel.allreduce_grads(self.policy_net.flat_grad)
-        self._update_avg_loss(loss)
-        self.optimizer.step()
+        self._update_avg_loss(loss)                 # synchronises (loss.item(), models/agent.py:166): the P2P error word rides with it
+        self.apply_gradients()
         # hard target sync with probability update_rate; np.random is seeded identically on every rank
         if np.random.random() < self.update_rate:
             print("target_net updated!")
             self.sync_target()
         return self.loss[(self.loss_position - 1) % self.loss_capacity]
+
+    def apply_gradients(self, check_every=1):
+        """clamp + Adam on policy_net.flat_grad; with torch.distributed initialised: synchronous data parallel — the gradients are
+        summed over the ranks first (RCCL over xGMI, or the opt-in one-shot P2P all-reduce fused with the update) and averaged
+        inside the kernel, so the clamp sees the averaged gradient as a single large batch would."""
+        _, world = self._world()
+        if world > 1:
+            from .. import parallel
+            parallel.data_parallel_step(self.policy_net, self.optimizer, check_every)
+        else:
+            self.optimizer.step()
 
     def sync_target(self):
         pn, tn = self.policy_net, self.target_net
@@ -282,9 +287,13 @@ class Agent(nn.Module):
 
     # ------------------------------------------------------------------ bookkeeping
     def _update_avg_loss(self, loss):
+        self.note_loss(float(loss.detach().to("cpu").reshape(-1)[0]))
+
+    def note_loss(self, value):
+        """The 32-entry loss ring of the reference (models/agent.py:198-203), fed with a host float."""
         if len(self.loss) < self.loss_capacity:
             self.loss.append(None)
-        self.loss[self.loss_position] = float(loss.detach().to("cpu").reshape(-1)[0])
+        self.loss[self.loss_position] = float(value)
         self.loss_position = (self.loss_position + 1) % self.loss_capacity
         self.loss_avg = sum(self.loss) / len(self.loss)
 

@@ -19,14 +19,15 @@ def init(backend=None):
     """Initialise from the torchrun environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*). Returns (rank, world, device)."""
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("IVOSW_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", 0)))      # tests put two ranks on one GPU
     use_gpu = torch.cuda.is_available()
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world)
+        backend = backend or os.environ.get("IVOSW_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -66,12 +67,22 @@ class P2PAllReduce:
 
     ``P2PAllReduce.create(n, device)`` is collective: every rank allocates its arena, the IPC handles go round with
     ``all_gather_object``, every rank maps the peers and the path is SELF-TESTED against ``dist.all_reduce`` on random data;
-    unless every rank passes, all of them get ``None`` back (and use RCCL).  ``IVOSW_P2P=0`` disables it."""
+    unless every rank passes, all of them get ``None`` back (and use RCCL).
+
+    OPT-IN (``IVOSW_P2P=1``): the cross-GPU write path has only ever run between two processes on one MI355X, so the product
+    default is the backend's all-reduce (RCCL over xGMI) until an 8-GPU node has validated it; ``bench.py --gpus N`` times both.
+    ``IVOSW_P2P_SELFTEST_FAIL=<rank>`` makes that rank report a failed self-test (fault injection: every rank must then end up
+    on the backend path).  A peer that does not arrive within ``timeout_ms`` does NOT hang the GPU and is NOT silent either: the
+    reduce kernels leave their outputs untouched and set the arena's error word, which ``check()`` reads (every call in
+    ``Agent.update_agent``, which synchronises for its loss anyway; every ``every`` calls in the lean loops) and turns into a
+    RuntimeError — after a timeout the parity double-buffering no longer holds, so the step cannot simply be retried."""
 
     def __init__(self):
         self.arena = None
         self.peers = []
         self.epoch = 0
+        self.calls_since_check = 0
+        self.collective = False         # create() reached its collective phase: teardown must be collective too
 
     @classmethod
     def create(cls, n, device, timeout_ms=2000):
@@ -79,9 +90,10 @@ class P2PAllReduce:
         from . import _lib as L
         w, r = world(), rank()
         device = torch.device(device)
-        if w < 2 or device.type != "cuda" or os.environ.get("IVOSW_P2P", "1") == "0":
+        if w < 2 or device.type != "cuda" or os.environ.get("IVOSW_P2P", "0") != "1":
             return None
         self, ok = cls(), True
+        self.collective = True
         self.n, self.rank, self.world, self.device, self.timeout_ms = int(n), r, w, device, int(timeout_ms)
         lib = L.lib()
         hb = lib.ivosw_p2p_handle_bytes()
@@ -130,6 +142,8 @@ class P2PAllReduce:
                     ok = ok and self.error() == 0 and bool(torch.allclose(got, want, rtol=1e-5, atol=1e-5 * float(want.abs().max()) + 1e-30))
                 except Exception:
                     ok = False
+            if os.environ.get("IVOSW_P2P_SELFTEST_FAIL", "") == str(r):
+                ok = False                                  # fault injection
             ok = _all_ranks_agree(ok, device)
         if not ok:
             self.close()
@@ -145,6 +159,20 @@ class P2PAllReduce:
                                             self.timeout_ms, L.stream_ptr(flat.device)), "p2p_allreduce")
         return flat
 
+    def fused_step(self, brain, optimizer):
+        """All-reduce of ``brain.flat_grad`` + clamp + Adam in TWO launches (push; wait + rank-ordered sum + clamp + Adam):
+        ``ivosw_p2p_allreduce_clamp_adam``.  flat_grad is left holding the SUM over ranks; the optimizer's step counter advances."""
+        from . import _lib as L
+        optimizer._ensure()
+        g = optimizer.param_groups[0]
+        optimizer.state["step"] += 1
+        self.epoch += 1
+        flat, grad = brain.flat, brain.flat_grad
+        L.check(L.lib().ivosw_p2p_allreduce_clamp_adam(
+            L.dptr(grad), L.dptr(grad), self.n, self.rank, self.world, self.table, self.epoch, self.timeout_ms, L.dptr(flat),
+            L.dptr(optimizer.state["exp_avg"]), L.dptr(optimizer.state["exp_avg_sq"]), optimizer.state["step"], g["lr"], g["betas"][0],
+            g["betas"][1], g["eps"], g["weight_decay"], g["clamp"], L.stream_ptr(flat.device)), "p2p_allreduce_clamp_adam")
+
     def error(self):
         import ctypes as C
         from . import _lib as L
@@ -152,19 +180,34 @@ class P2PAllReduce:
         L.check(L.lib().ivosw_p2p_error(C.c_void_p(self.arena), C.byref(e)), "p2p_error")
         return e.value
 
+    def check(self, every=1):
+        """Read the arena's error word every ``every`` calls (a 4-byte D2H copy, i.e. a stream synchronisation) and raise on a
+        peer timeout.  The ranks that did arrive time out in turn on the missing peer and raise too."""
+        self.calls_since_check += 1
+        if self.calls_since_check < every:
+            return
+        self.calls_since_check = 0
+        if self.error() != 0:
+            raise RuntimeError(f"ivos-w P2P all-reduce: rank {self.rank} waited more than {self.timeout_ms} ms for a peer's gradient; "
+                               "the replicas are no longer synchronised (nothing was applied for that step). Restart from the last "
+                               "checkpoint, with IVOSW_P2P=0 to use the backend's all-reduce.")
+
     def close(self):
+        """Collective whenever create() reached its collective phase, in the order synchronise -> barrier -> unmap peers -> free:
+        no rank unmaps or frees while one of its own pushes, or a peer's, may still be writing."""
         from . import _lib as L
         lib = L.lib()
+        if self.collective and dist.is_initialized():
+            try:
+                torch.cuda.synchronize(self.device)
+                dist.barrier()
+            except Exception:
+                pass
+        self.collective = False
         for p in self.peers:
             lib.ivosw_p2p_close(p)
         self.peers = []
         if self.arena:
-            if dist.is_initialized():
-                try:
-                    torch.cuda.synchronize(self.device)
-                    dist.barrier()                          # nobody unmaps / frees while a peer may still write
-                except Exception:
-                    pass
             lib.ivosw_p2p_free(self.arena)
             self.arena = None
 
@@ -196,22 +239,75 @@ def p2p_for(flat_grad):
     return _P2P[key]
 
 
-def allreduce_grads(flat_grad):
+def _backend_allreduce(flat_grad):
+    if flat_grad.is_cuda and dist.get_backend() == "gloo":
+        # hosts without RCCL (and the two-ranks-on-one-GPU tests): stage the 724 KB arena through host memory
+        h = flat_grad.to("cpu")
+        dist.all_reduce(h)
+        flat_grad.copy_(h)
+    else:
+        dist.all_reduce(flat_grad)            # RCCL over xGMI
+
+
+def allreduce_grads(flat_grad, check_every=1):
     """Sum the flat gradient arena over ranks in place; returns the scale (1/world) the optimizer must apply.
-    Path: the one-shot xGMI peer-to-peer all-reduce when every rank's self-test passed (P2PAllReduce), else RCCL."""
+    Path: the one-shot xGMI peer-to-peer all-reduce when it is enabled and every rank's self-test passed, else the backend's."""
     w = world()
     if w > 1:
         p2p = p2p_for(flat_grad) if flat_grad.is_cuda else None
         if p2p is not None:
             p2p(flat_grad)
-        elif flat_grad.is_cuda and dist.get_backend() == "gloo":
-            # hosts without RCCL (and the two-ranks-on-one-GPU test): stage the 724 KB arena through pinned host memory
-            h = flat_grad.to("cpu")
-            dist.all_reduce(h)
-            flat_grad.copy_(h)
+            p2p.check(check_every)
         else:
-            dist.all_reduce(flat_grad)        # RCCL over xGMI
+            _backend_allreduce(flat_grad)
     return 1.0 / w
+
+
+def collective_path(flat_grad):
+    """'p2p' | 'backend' | None (single process): which all-reduce the data-parallel step of this process uses."""
+    if world() < 2:
+        return None
+    return "p2p" if (flat_grad.is_cuda and p2p_for(flat_grad) is not None) else "backend"
+
+
+def data_parallel_step(brain, optimizer, check_every=1):
+    """The exchange step of synchronous data parallelism + the optimizer step, on every rank: gradients summed over ranks, scaled by
+    1/world INSIDE the clamp + Adam kernel (the clamp of models/agent.py:157-159 sees the averaged gradient, as one large batch
+    would).  P2P path: two launches (push | wait + sum + clamp + Adam); backend path: all-reduce, then the fused clamp + Adam."""
+    w = world()
+    if w < 2:
+        optimizer.grad_scale = 1.0
+        optimizer.step()
+        return
+    grad = brain.flat_grad
+    p2p = p2p_for(grad) if grad.is_cuda else None
+    if p2p is not None and os.environ.get("IVOSW_P2P_FUSED", "1") != "0":
+        p2p.fused_step(brain, optimizer)
+        p2p.check(check_every)
+    else:
+        optimizer.grad_scale = allreduce_grads(grad, check_every)
+        optimizer.step()
+
+
+class RankBatchSampler:
+    """The DataLoader's shuffled minibatches, dealt out to the ranks: ONE permutation of the dataset per epoch from a shared seed
+    (identical on every rank), cut into batches of ``batch_size``; rank r takes batches r, r + world, ...  — so a data-parallel
+    step consumes ``world`` consecutive minibatches of the single-process order, and every rank runs the same number of steps
+    (a trailing group of fewer than ``world`` batches is dropped)."""
+
+    def __init__(self, n, batch_size, rank_, world_, seed):
+        self.n, self.batch_size, self.rank, self.world, self.seed = int(n), int(batch_size), int(rank_), int(world_), int(seed)
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed)
+        perm = torch.randperm(self.n, generator=g).tolist()
+        batches = [perm[i:i + self.batch_size] for i in range(0, self.n, self.batch_size)]
+        for k in range(len(self)):
+            yield batches[k * self.world + self.rank]
+
+    def __len__(self):
+        return -(-self.n // self.batch_size) // self.world
 
 
 def shared_coin(rng):

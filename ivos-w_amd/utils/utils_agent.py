@@ -203,10 +203,63 @@ def agent_business(cfg_yl, agent, max_nb_interactions, n_interaction, first_scri
                                 _annotation_counts(n, nxt), old_masks_metric, new_masks_metric, old_masks_meta,
                                 new_masks_meta, done, old_frame, report_save_dir)
     if n_interaction == max_nb_interactions and cfg_yl.phase == "train":
-        losses = []
-        for i, sample in enumerate(agent_train_loader):
-            if i == max_nb_interactions * 3 - 1:          # at most 3*max_nb_interactions - 1 DQN steps per episode
-                break
-            losses.append(agent.update_agent(sample))
+        max_steps = max_nb_interactions * 3 - 1           # at most 3*max_nb_interactions - 1 DQN steps per episode
+        losses = _device_update_loop(agent, agent_train_loader, max_steps)
+        if losses is None:                                # a foreign loader: the reference's loop, one update_agent per collated batch
+            losses = []
+            for i, sample in enumerate(agent_train_loader):
+                if i == max_steps:
+                    break
+                losses.append(agent.update_agent(sample))
         agent_loss_iter = np.array(losses).mean()
     return agent_loss_iter, reward_step, reward_done
+
+
+def _device_update_loop(agent, loader, max_steps):
+    """The episode's DQN updates (reference utils/utils_agent.py:244-252) without the per-step host traffic, when the loader is a
+    plain DataLoader over this build's own replay dataset (datasets/agent_dataset.py): the dataset's SoA is uploaded once
+    (DeviceReplay), the loader's OWN batch sampler supplies the minibatch indices — the same indices, drawn from torch's global
+    generator in the same order as iterating the loader would (its base seed first, then the sampler's) — each step gathers its
+    minibatch on the device and runs loss + gradients + [all-reduce] + clamp + Adam + the host coin, and the losses come back in ONE
+    device-to-host copy at the end.  Same minibatches, same arithmetic, same coin and RNG streams as ``agent.update_agent(sample)``
+    per collated batch: losses, parameters and the agent's loss ring are bit-identical (tests/test_gpu_agent.py).
+    Returns the list of losses, or None when the loader is not of that kind (``IVOSW_UPDATE_PATH=host`` forces None)."""
+    import os
+    ds = getattr(loader, "dataset", None)
+    bs = getattr(loader, "batch_sampler", None)
+    if os.environ.get("IVOSW_UPDATE_PATH", "") == "host" or ds is None or bs is None or not hasattr(ds, "to_device_replay"):
+        return None
+    if getattr(loader, "num_workers", 0) != 0 or getattr(loader, "collate_fn", None) is not torch.utils.data.default_collate \
+            or getattr(ds, "transform", None) is not None or len(ds) == 0:
+        return None
+    dev = torch.device(agent.device)
+    if dev.type != "cuda":
+        return None
+    replay = getattr(ds, "_device_replay", None)
+    if replay is None or replay.device != dev:
+        replay = ds._device_replay = ds.to_device_replay(dev)
+    # what DataLoader.__iter__ draws from the global generator before the sampler's own seed (torch/utils/data/dataloader.py,
+    # _BaseDataLoaderIter.__init__: the base seed), so that the global RNG stream stays the one of the per-batch loop
+    torch.empty((), dtype=torch.int64).random_(generator=getattr(loader, "generator", None))
+    steps = []
+    for i, idx in enumerate(bs):
+        if i == max_steps:
+            break
+        steps.append(list(idx))
+    if not steps:
+        return []
+    flat = torch.as_tensor([j for st in steps for j in st], dtype=torch.int64).to(dev)       # one upload for the whole episode
+    loss_dev = torch.empty(len(steps), dtype=torch.float32, device=dev)
+    off = 0
+    for k, st in enumerate(steps):
+        batch = replay.sample(flat[off:off + len(st)])
+        off += len(st)
+        loss_dev[k:k + 1].copy_(agent.loss_and_grads(batch))
+        agent.apply_gradients(check_every=len(steps))
+        if np.random.random() < agent.update_rate:
+            print("target_net updated!")
+            agent.sync_target()
+    losses = [float(v) for v in loss_dev.cpu().numpy()]
+    for v in losses:
+        agent.note_loss(v)
+    return losses

@@ -191,8 +191,16 @@ def make_assess():
     with open(os.path.join(HERE, "assessnet_keys.json"), "w") as f:
         json.dump([[k, list(v.shape)] for k, v in net.state_dict().items()], f)
     out = {}
-    for tag, B, edge in (("B8", 8, True), ("B1", 1, False), ("B3", 3, False)):
-        tf, tp = synth.assess_inputs(B, seed=1234 + B, edge_cases=edge, structured=True)
+    # S8: the B8 inputs (edge masks included) through the reference with the SPREAD weight recipe (synth.assessnet_state_dict(0,
+    # spread=True)): the default recipe's scores lie within 4 % of each other, so a 1e-4 check on them has little power against,
+    # say, a wrong tap in res5; the spread recipe's scores differ by far more than any tolerance from frame to frame
+    net_spread = AssessNet()
+    net_spread.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.assessnet_state_dict(0, spread=True).items()}, strict=True)
+    net_spread.eval()
+    net_default = net
+    for tag, B, edge in (("B8", 8, True), ("B1", 1, False), ("B3", 3, False), ("S8", 8, True)):
+        net = net_spread if tag == "S8" else net_default
+        tf, tp = synth.assess_inputs(B, seed=1234 + (8 if tag == "S8" else B), edge_cases=edge, structured=True)
         taps = {}
         hooks = []
         enc = net.Encoder

@@ -79,3 +79,26 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_rank_batch_sampler_deals_the_shuffled_minibatches_out():
+    """parallel.RankBatchSampler: one shared permutation per epoch, cut into minibatches, rank r takes batches r, r + world, ...:
+    the ranks' batches of a data-parallel step are disjoint, together they are `world` consecutive minibatches of the single-process
+    order, every rank runs the same number of steps, and the deal is a pure function of the shared seed."""
+    from ivos_w_amd.parallel import RankBatchSampler
+    n, B, world = 103, 8, 2
+    per_rank = [list(RankBatchSampler(n, B, r, world, seed=77)) for r in range(world)]
+    assert len(per_rank[0]) == len(per_rank[1]) == len(RankBatchSampler(n, B, 0, world, 77)) == (-(-n // B)) // world
+    g = torch.Generator()
+    g.manual_seed(77)
+    perm = torch.randperm(n, generator=g).tolist()
+    single = [perm[i:i + B] for i in range(0, n, B)]
+    for k in range(len(per_rank[0])):
+        assert per_rank[0][k] == single[2 * k] and per_rank[1][k] == single[2 * k + 1]
+        assert not set(per_rank[0][k]) & set(per_rank[1][k])
+    assert list(RankBatchSampler(n, B, 1, world, seed=77)) == per_rank[1]
+    assert list(RankBatchSampler(n, B, 1, world, seed=78)) != per_rank[1]
+    # a DataLoader takes it as its batch sampler
+    from torch.utils.data import DataLoader
+    dl = DataLoader(list(range(n)), batch_sampler=RankBatchSampler(n, B, 0, world, 77))
+    assert [b.tolist() for b in dl] == per_rank[0]

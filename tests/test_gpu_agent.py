@@ -412,3 +412,56 @@ def test_train_phase_epsilon_greedy_vs_reference_golden(dev, golden_dir):
         assert ("randomly" in buf.getvalue()) == want["random"], i
         assert int(a) == want["action"] and agent.steps_done == want["steps_done"], (i, int(a), want)
     assert sum(not c["random"] for c in gold["calls"]) >= 5          # the fixture does exercise the greedy branch
+
+
+def _synthetic_replay_dataset(n=300, T=25, seed=3):
+    """A DAVIS2017AgentTrain without the CSV round trip: the same per-sample dicts (datasets/agent_dataset.py) over a synthetic SoA."""
+    from ivos_w_amd.datasets.agent_dataset import DAVIS2017AgentTrain
+    soa = synth.replay_transitions(n=n, T=T, seed=seed)
+    ds = object.__new__(DAVIS2017AgentTrain)
+    ds.transform, ds.soa = None, soa
+    ds.samples_list = [
+        dict(action=soa["action"][i], old_state_iou=soa["old_state_iou"][i][None], new_state_iou=soa["new_state_iou"][i][None],
+             annotated_frames=soa["annotated_frames"][i][None], next_annotated_frames=soa["next_annotated_frames"][i][None],
+             reward_step=soa["reward_step"][i], reward_done=soa["reward_done"][i], done=soa["done"][i]) for i in range(n)]
+    return ds
+
+
+def test_agent_business_device_update_loop_equals_the_per_batch_loop(dev, capsys, monkeypatch):
+    """agent_business's update loop (reference utils/utils_agent.py:244-252: up to 14 update_agent calls on collated DataLoader
+    batches, eight small H2D copies and a loss.item() each) against the device loop it takes when the loader is this build's own
+    dataset: SoA uploaded once, minibatch indices from the loader's own batch sampler, one D2H of the losses per episode.  Same
+    minibatches, arithmetic, coins and generator streams -> losses, parameters, Adam state, target net, the agent's loss ring and
+    torch's / numpy's generator states are bit-identical after two episodes."""
+    from torch.utils.data import DataLoader
+    from ivos_w_amd.models.agent import Agent
+    from ivos_w_amd.utils import utils_agent
+    ds = _synthetic_replay_dataset()
+    out = {}
+    for path in ("host", "device"):
+        monkeypatch.setenv("IVOSW_UPDATE_PATH", "host" if path == "host" else "")
+        torch.manual_seed(123)
+        np.random.seed(5)
+        agent = Agent(dev, cfg(update_rate=0.3))
+        load_brain(agent.policy_net, 0)
+        load_brain(agent.target_net, 1)
+        losses = []
+        for episode in range(2):
+            loader = DataLoader(ds, batch_size=32, shuffle=True, num_workers=0)
+            got = utils_agent._device_update_loop(agent, loader, 14)
+            if path == "host":
+                assert got is None
+                got = []
+                for i, sample in enumerate(loader):
+                    if i == 14:
+                        break
+                    got.append(agent.update_agent(sample))
+            assert got is not None and len(got) == min(14, -(-len(ds) // 32))
+            losses.append(np.array(got))
+        out[path] = (np.concatenate(losses), agent.policy_net.flat.cpu().numpy(), agent.target_net.flat.cpu().numpy(),
+                     agent.optimizer.state["exp_avg"].cpu().numpy(), list(agent.loss), agent.loss_position, agent.optimizer.state["step"],
+                     torch.get_rng_state().numpy().copy(), np.random.get_state()[1].copy())
+    capsys.readouterr()
+    for a, b in zip(out["host"], out["device"]):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    assert out["host"][6] == 2 * 10 and np.all(out["host"][0] > 0)           # 300 transitions / 32 -> 10 minibatches per episode

@@ -90,6 +90,29 @@ def test_fp32_taps_and_scores_vs_reference_golden(dev, gold, net32, tag, B, edge
     np.testing.assert_allclose(score, gold[f"{tag}_score"], rtol=1e-4)
 
 
+def test_spread_weights_vs_reference_golden(dev, gold):
+    """The S8 fixture: the reference itself run (tests/golden/make_goldens.py) on the B8 inputs, edge masks included, with the SPREAD
+    weight recipe — scores that differ from frame to frame by 5.5 % of their mean, 550 x the 1e-4 tolerance (the default recipe's
+    lie within 4 % of each other, which gives a check on nearly constant outputs little power).  fp32 mode: every tap and the
+    scores at the north-star tolerance, and the frame-to-frame DIFFERENCES too; bf16 mode: the stated bf16 tolerance."""
+    _, _, ttf, ttp = inputs(dev, 8, True)
+    n32, n16 = make_net(dev, "fp32", spread=True), make_net(dev, "bf16", spread=True)
+    ref = gold["S8_score"]
+    assert np.ptp(ref) > 0.05 * np.abs(ref).mean()
+    for nm in ("stem", "pool", "res2", "res3", "res4", "res5"):
+        _, t = n32.forward_tap(ttf, ttp, nm)
+        a = t.cpu().numpy().transpose(0, 3, 1, 2)
+        np.testing.assert_allclose(_slice4(a), gold[f"slice_S8_{nm}"], rtol=1e-3, atol=3e-4, err_msg=nm)
+        np.testing.assert_allclose(_stat(a), gold[f"stat_S8_{nm}"], rtol=2e-5, err_msg=nm)
+    s32 = n32(ttf, ttp).cpu().numpy()
+    np.testing.assert_allclose(s32, ref, rtol=1e-4)
+    np.testing.assert_allclose(s32 - s32.mean(), ref - ref.mean(), atol=1e-4 * np.abs(ref).max())
+    assert np.array_equal(np.argsort(s32.ravel()), np.argsort(ref.ravel()))           # the frames rank as in the reference
+    s16 = n16(ttf, ttp).cpu().numpy()
+    np.testing.assert_allclose(s16, ref, rtol=BF16_SCORE_RTOL)
+    print(f"spread fixture: fp32 worst rel {np.max(np.abs(s32 - ref) / np.abs(ref)):.2e}, bf16 worst rel {np.max(np.abs(s16 - ref) / np.abs(ref)):.2e}")
+
+
 def test_fp32_b3_and_chunking(dev, gold):
     _, _, ttf, ttp = inputs(dev, 3, False)
     net = make_net(dev, "fp32", chunk=2)                  # ragged last chunk

@@ -39,11 +39,14 @@ def _batch(tr, idx):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.collate_np(tr, idx).items()}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="backend"):
     import io
     import contextlib
     from ivos_w_amd import parallel
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      IVOSW_P2P="0" if mode == "backend" else "1")
+    if mode == "p2p_fault":
+        os.environ["IVOSW_P2P_SELFTEST_FAIL"] = "1"          # rank 1 reports a failed self-test: BOTH ranks must end up on the backend path
     r, w, dev = parallel.init("gloo")
     assert dev.type == "cuda" and w == 2
     tr = synth.replay_transitions(n=2000, T=25, seed=2019)
@@ -56,13 +59,24 @@ def _worker(rank, world, port, q):
             agent.update_agent(_batch(tr, idx[rank * (B // 2):(rank + 1) * (B // 2)]))
             out.append((agent.policy_net.flat_grad.cpu().numpy().copy(), agent.policy_net.flat.cpu().numpy().copy(),
                         agent.target_net.flat.cpu().numpy().copy()))
-    assert agent.optimizer.grad_scale == 0.5
+    path = parallel.collective_path(agent.policy_net.flat_grad)
+    assert path == ("p2p" if mode == "p2p" else "backend"), (mode, path)
+    if path == "backend":
+        assert agent.optimizer.grad_scale == 0.5
     q.put((rank, out))
+    for v in parallel._P2P.values():
+        if v is not None:
+            v.close()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_world2_product_path_matches_single_process_full_batch():
+@pytest.mark.parametrize("mode", ["backend", "p2p", "p2p_fault"])
+def test_world2_product_path_matches_single_process_full_batch(mode):
+    """mode: 'backend' = the product default (torch.distributed all-reduce, then clamp + Adam with 1/world); 'p2p' = IVOSW_P2P=1: the
+    one-shot peer-to-peer all-reduce FUSED with clamp + Adam (push | wait + rank-ordered sum + clamp + Adam: two launches);
+    'p2p_fault' = P2P requested but rank 1's self-test is made to fail (IVOSW_P2P_SELFTEST_FAIL): every rank must then use the
+    backend collective."""
     import io
     import contextlib
     s_ = socket.socket()
@@ -71,7 +85,7 @@ def test_world2_product_path_matches_single_process_full_batch():
     s_.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(2))
@@ -136,14 +150,16 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     assert d["config"]["parallelism"] == "frames sharded x2" and "cpu_baseline" not in d
     assert d["dqn"]["value"] > 0 and "all-reduce" in d["dqn"]["collective"]
     if variant == "default":
-        assert "peer-to-peer" in d["dqn"]["collective"] and d["dqn"]["graph"] is False
+        legs = d["dqn"]["collectives"]                       # both collective paths are timed; the faster validated one is dqn.value
+        assert set(legs) == {"backend", "p2p"} and all(v.get("us_per_step", 0) > 0 for v in legs.values()), legs
+        assert d["dqn"]["graph"] is False
     else:
         assert "gloo" in d["dqn"]["collective"] and d["dqn"]["graph"] is True
 
 
 def _p2p_worker(rank, world, port, q):
     from ivos_w_amd import parallel
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", IVOSW_P2P="1")
     r, w, dev = parallel.init("gloo")
     n = 180993
     p2p = parallel.P2PAllReduce.create(n, dev)
@@ -188,3 +204,78 @@ def test_p2p_allreduce_two_ranks_on_one_device():
         want = xs[0] + xs[1]                                   # rank order
         np.testing.assert_array_equal(res[0][it], want)
         np.testing.assert_array_equal(res[1][it], want)
+
+
+def _timeout_worker(rank, world, port, q):
+    from ivos_w_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", IVOSW_P2P="1")
+    r, w, dev = parallel.init("gloo")
+    n = 180993
+    p2p = parallel.P2PAllReduce.create(n, dev, timeout_ms=200)
+    outcome = "no p2p"
+    if p2p is not None:
+        x = torch.ones(n, device=dev) * (rank + 1)
+        keep = x.clone()
+        if rank == 0:                                          # rank 1 never shows up for this step
+            p2p(x)
+            try:
+                p2p.check()
+                outcome = "silent"
+            except RuntimeError as e:
+                outcome = "raised: " + str(e)[:60]
+            assert torch.equal(x, keep)                        # nothing was applied: the local gradient is NOT passed off as the sum
+        else:
+            outcome = "absent"
+    q.put((rank, outcome))
+    torch.distributed.barrier()
+    if p2p is not None:
+        p2p.close()
+    torch.distributed.destroy_process_group()
+
+
+def test_p2p_timeout_is_loud():
+    """A peer that does not arrive within the timeout: the reduce kernel leaves its output untouched and sets the arena's error
+    word; P2PAllReduce.check() turns it into a RuntimeError (round 2's path returned silently and kept the un-reduced gradient)."""
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0].startswith("raised: ivos-w P2P all-reduce"), res
+    assert res[1] == "absent"
+
+
+def test_train_agent_data_parallel_under_torchrun(tmp_path):
+    """train_agent.py (the entry point, not the bench) as a 2-rank data-parallel job exactly as torch.distributed.run launches it —
+    both ranks on this box's one GPU (IVOSW_LOCAL_DEVICE=0, gloo rendezvous).  Every rank plays the same episodes; the update
+    loop deals the shuffled minibatches out to the ranks and all-reduces the gradients.  Rank 0 writes the checkpoint and the
+    summary, which records that the replicas' parameter bits were compared and are identical."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    work = str(tmp_path)
+    env = dict(os.environ, IVOSW_LOCAL_DEVICE="0", IVOSW_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["with", "synthetic=1", f"ckpt_dir={work}/ckpt", f"agent.save_result_dir={work}/results", "num_epochs=1", "synth.n_sequences=2",
+            "synth.n_frames=26", "synth.height=120", "synth.width=216", "agent.train_batch_size=16", "agent.update_rate=0.3"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "train_agent.py")] + args
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    hist = json.load(open(os.path.join(work, "results", "train_summary.json")))
+    assert hist and hist[-1]["world"] == 2 and hist[-1]["replicas_identical"] is True and hist[-1]["collective"] == "backend"
+    assert hist[-1]["updates"] > 0
+    assert os.path.exists(os.path.join(work, "ckpt", "agent.pt"))
+    assert os.path.isdir(os.path.join(work, "results", "rank1")) and not os.path.exists(os.path.join(work, "results", "rank1", "train_summary.json"))
