@@ -9,9 +9,13 @@
  *   - extern "C", plain pointers + sizes.  No torch / HIP types in signatures: a stream is passed as
  *     void* (it is a hipStream_t; NULL = the null stream).
  *   - Every pointer is a DEVICE pointer owned by the caller unless a parameter says "host".
- *     The library never allocates or frees device memory and keeps no per-call state: workspaces are
- *     sized by the *_ws_bytes queries and handed in by the caller.
- *   - All calls are asynchronous on `stream`; nothing synchronises the device.
+ *     Workspaces are sized by the *_ws_bytes queries and handed in by the caller; the library keeps no
+ *     per-call state in them.  Two exceptions, both documented at their entry points: ivosw_p2p_alloc /
+ *     ivosw_p2p_free allocate the fine-grained peer-to-peer arena (a kind of memory neither torch nor a
+ *     caller can allocate), and ivosw_assess_forward keeps ONE helper stream + two events per device for
+ *     the two-stream split of a batch (created on first use, never freed).
+ *   - All calls are asynchronous on `stream`; nothing synchronises the device (except the entries that
+ *     return a host value: ivosw_p2p_error, ivosw_profile_*).
  *   - Return 0 on success, negative on error; ivosw_last_error() gives a thread-local message.
  *   - Not thread-safe per workspace; distinct workspaces on distinct streams are independent.
  */
@@ -256,6 +260,11 @@ int ivosw_bneck_probe(const void* x, void* y, const void* wa, const float* ba, c
 int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, const float* ba, const void* wb, const float* bb,
                            const void* wc, const float* bc, void* frag, int B, int H, int W, int Cin, int Cmid,
                            unsigned long long* ts, ivosw_stream_t stream);
+
+/* Measurement aid (bench.py roofline.sclk_mhz): one wave spins for spin_us of wall time and writes {shader cycles, 100 MHz wall
+ * ticks} of that interval to out2 (2 x uint64, device): launched on a side stream beside the measured work, cycles / ticks x 100 MHz
+ * is the shader clock the chip ran at under that load.                                                                       */
+int ivosw_clock_probe(unsigned long long* out2, int spin_us, ivosw_stream_t stream);
 
 /* Tuning probe: ONE launch of the res2 stage kernel (the three bottlenecks of res2 + res3's forwarded conv1; reference
  * models/assessment.py:58-59) on x [B,64,64,64] bf16 with the weights of a packed bf16 arena (ivosw_assess_pack); y [B,64,64,256]

@@ -227,10 +227,12 @@ static size_t ws_single(int dtype, int B, int chunk) {
 // MFMA-bound phases of the other's (2 x 128 frames: 63.2 k -> 65.8 k frames/s on one box, tools/two_stream_probe.py; four
 // quarters are slower; at eval sizes: B = 100 + 7 %, 160 + 13 %, 300 + 12 %, 64 + 0.3 %, tools/split_min_sweep.sh).  Per-frame results do not depend on the batch a frame travels in (tests: chunk schedules, batch
 // permutations, B = 256 against B = 8 / 64), so the split is invisible in the scores.  Each half gets its own workspace.
-static bool split_wanted(int dtype, int B, int chunk, int tap_stage) {
-    return (dtype == IVOSW_BF16 || tune_get("STREAMS2_F32", 1)) && chunk <= 0 && tap_stage == 0 && tune_get("STREAMS2", 1) && B >= std::max(2, tune_get("STREAMS2_MIN", 64));
-}
 static int split_first_half(int B) { return (B / 2 + 7) / 8 * 8; }
+static bool split_wanted(int dtype, int B, int chunk, int tap_stage) {
+    // both halves must be non-empty whatever STREAMS2_MIN is tuned to: ceil8(B / 2) reaches B for B <= 8
+    return (dtype == IVOSW_BF16 || tune_get("STREAMS2_F32", 1)) && chunk <= 0 && tap_stage == 0 && tune_get("STREAMS2", 1) &&
+           B >= std::max(2, tune_get("STREAMS2_MIN", 64)) && split_first_half(B) < B;
+}
 static size_t ws_split(int dtype, int B) {
     const int B0 = split_first_half(B);
     return align_up(ws_single(dtype, B0, 0), 256) + ws_single(dtype, B - B0, 0);

@@ -267,3 +267,32 @@ extern "C" int ivosw_roi_sample(const float* tf, const float* tp, const float* y
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
+
+// ---------------------------------------------------------------- shader-clock probe (measurement aid, bench.py roofline.sclk_mhz)
+// One wave spins for `spin_us` of wall time and reports {shader cycles (s_memtime), 100 MHz wall ticks (s_memrealtime)} of the
+// interval: launched on a side stream beside a forward pass it gives the shader clock the chip actually ran at under that load
+// (the chip clocks to its power budget: DESIGN section 5).  out: 2 x uint64 on the device.
+namespace ivosw {
+__global__ void clock_probe_kernel(unsigned long long* __restrict__ out, unsigned long long spin_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = wall_clock64();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = wall_clock64();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[0] = t1 - t0;
+    out[1] = wall_clock64() - r0;
+}
+}  // namespace ivosw
+
+extern "C" int ivosw_clock_probe(unsigned long long* out2, int spin_us, ivosw_stream_t stream) {
+    using namespace ivosw;
+    IVOSW_REQUIRE(out2 && spin_us > 0 && spin_us <= 1000000, "null pointer / spin_us out of range");
+    IVOSW_ON_DEVICE_OF(out2);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), out2, (unsigned long long)spin_us * 100ull);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(512) void bneck64_kernel(BneckArgs p) {
                     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     unsigned pk[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pk[k] = pack2_bf16(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
+                    for (int k = 0; k < 4; ++k) pk[k] = relu2_bf16(v[2 * k], v[2 * k + 1]);
                     if (!ABL(p.debug, 2) || pk[0] == 0x12345678u) {
                         u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
                         if (p.nt) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(Yb + goff(cp, q, it)));

@@ -179,8 +179,8 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 pk;
-                    pk.x = pack2_bf16(fmaxf(a[4 * g] + bq[g].x, 0.f), fmaxf(a[4 * g + 1] + bq[g].y, 0.f));
-                    pk.y = pack2_bf16(fmaxf(a[4 * g + 2] + bq[g].z, 0.f), fmaxf(a[4 * g + 3] + bq[g].w, 0.f));
+                    pk.x = relu2_bf16(a[4 * g] + bq[g].x, a[4 * g + 1] + bq[g].y);
+                    pk.y = relu2_bf16(a[4 * g + 2] + bq[g].z, a[4 * g + 3] + bq[g].w);
                     lds_write_b64(lds_base + (ct >> 1) * SLICE + px * ROWB + ((((ct & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf_, pk);
                 }
             }
@@ -362,7 +362,7 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
                     unsigned pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                        pk[k] = relu2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u));
                     *reinterpret_cast<uint4*>(Y + (size_t)(i * 32 + pr) * CIN + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
                 if (item < NACC - 1) { rr[0] = rn[0]; rr[1] = rn[1]; }
@@ -553,8 +553,8 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 pk;
-                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
-                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y) & (in ? 0xffffffffu : 0u);
+                    pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w) & (in ? 0xffffffffu : 0u);
                     lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
             }
@@ -630,8 +630,8 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 pk;
-                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
-                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
+                pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y);
+                pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w);
                 lds_write_b64(lds_base + (ctw >> 1) * T2S + px * ROWB + ((((ctw & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
             }
         }
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                     unsigned pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                        pk[k] = relu2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u));
                     *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
                 if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
@@ -863,8 +863,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo128s_kernel(BneckWideArgs p)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 pk;
-                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
-                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y) & (in ? 0xffffffffu : 0u);
+                    pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w) & (in ? 0xffffffffu : 0u);
                     lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
             }
@@ -937,8 +937,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo128s_kernel(BneckWideArgs p)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 pk;
-                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
-                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
+                pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y);
+                pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w);
                 lds_write_b64(lds_base + (ctw >> 1) * T2S + px * ROWB + ((((ctw & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
             }
         }
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo128s_kernel(BneckWideArgs p)
                     unsigned pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                        pk[k] = relu2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u));
                     *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
                 if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
@@ -1160,8 +1160,8 @@ __global__ __launch_bounds__(512) void bneck_half16_kernel(BneckWideArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 pk;
-                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
-                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y) & (in ? 0xffffffffu : 0u);
+                    pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w) & (in ? 0xffffffffu : 0u);
                     lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
             }
@@ -1235,8 +1235,8 @@ __global__ __launch_bounds__(512) void bneck_half16_kernel(BneckWideArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 u32x2 pk;
-                pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f));
-                pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f));
+                pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y);
+                pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w);
                 lds_write_b64(lds_base + (ctw >> 1) * T2S + px * ROWB + ((((ctw & 1) * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
             }
         }
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(512) void bneck_half16_kernel(BneckWideArgs p) {
                     unsigned pk[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                        pk[k] = relu2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u));
                     *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
                 if (i < 3) { rr[0] = rn[0]; rr[1] = rn[1]; }
@@ -1509,8 +1509,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     u32x2 pk;
-                    pk.x = in ? pack2_bf16(fmaxf(acc[i][4 * g] + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + bq[g].y, 0.f)) : 0u;
-                    pk.y = in ? pack2_bf16(fmaxf(acc[i][4 * g + 2] + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + bq[g].w, 0.f)) : 0u;
+                    pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y) & (in ? 0xffffffffu : 0u);
+                    pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w) & (in ? 0xffffffffu : 0u);
                     if (PAD) lds_write_b64(lds_base + T1_OFF + hr * T1R + ((ctw * 4 + g) << 4) + 8 * lhalf, pk);
                     else lds_write_b64(lds_base + T1_OFF + hr * ROWB + (((ctw * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
@@ -1610,8 +1610,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
                 for (int g = 0; g < 4; ++g) {
                     const float4 o = *reinterpret_cast<const float4*>(scr + ((i * 4 + g) * 64 + lane) * 4);
                     u32x2 pk;
-                    pk.x = pack2_bf16(fmaxf(acc[i][4 * g] + o.x + bq[g].x, 0.f), fmaxf(acc[i][4 * g + 1] + o.y + bq[g].y, 0.f));
-                    pk.y = pack2_bf16(fmaxf(acc[i][4 * g + 2] + o.z + bq[g].z, 0.f), fmaxf(acc[i][4 * g + 3] + o.w + bq[g].w, 0.f));
+                    pk.x = relu2_bf16(acc[i][4 * g] + o.x + bq[g].x, acc[i][4 * g + 1] + o.y + bq[g].y);
+                    pk.y = relu2_bf16(acc[i][4 * g + 2] + o.z + bq[g].z, acc[i][4 * g + 3] + o.w + bq[g].w);
                     lds_write_b64(lds_base + T2_OFF + px * ROWB + (((ctw * 4 + g) ^ ((px >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
             }
@@ -1751,8 +1751,8 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
                 for (int g = 0; g < 4; ++g) {
                     const float4 bq = *reinterpret_cast<const float4*>(p.bd + ct * 32 + 8 * g + 4 * lhalf);
                     uint2 pk;
-                    pk.x = pack2_bf16(fmaxf(ad[4 * g] + bq.x, 0.f), fmaxf(ad[4 * g + 1] + bq.y, 0.f));
-                    pk.y = pack2_bf16(fmaxf(ad[4 * g + 2] + bq.z, 0.f), fmaxf(ad[4 * g + 3] + bq.w, 0.f));
+                    pk.x = relu2_bf16(ad[4 * g] + bq.x, ad[4 * g + 1] + bq.y);
+                    pk.y = relu2_bf16(ad[4 * g + 2] + bq.z, ad[4 * g + 3] + bq.w);
                     *reinterpret_cast<uint2*>(o + 8 * g) = pk;
                 }
             }
@@ -1788,7 +1788,7 @@ __global__ __launch_bounds__(512, 4) void bneck_halo64s_kernel(BneckWideArgs p) 
                 unsigned pk[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    pk[k] = pack2_bf16(fmaxf(v[2 * k] + __uint_as_float(w4[k] << 16), 0.f), fmaxf(v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), 0.f));
+                    pk[k] = relu2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u));
                 if constexpr (YS2) {
                     if (it == 0 && !(prr & 1)) *reinterpret_cast<uint4*>(yrow + (size_t)i * (HW / 2) * COUT) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 } else {
@@ -1959,9 +1959,7 @@ __global__ __launch_bounds__(512) void conv1x1_wide_kernel(ConvArgs p, const voi
             unsigned pk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float lo = v[2 * k] + __uint_as_float(w4[k] << 16), hi = v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u);
-                if (p.relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                pk[k] = pack2_bf16(lo, hi);
+                pk[k] = act2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u), p.relu != 0);
             }
             if (m < M) {
                 u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};

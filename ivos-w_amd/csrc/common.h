@@ -99,6 +99,30 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
     return x.u;
 }
 
+// ReLU AFTER the bf16 conversion, on the packed pair, as ONE integer instruction (v_pk_max_i16 against 0: a negative bf16 is a
+// negative int16, -0 becomes +0): the same bits as pack2_bf16(fmaxf(lo, 0), fmaxf(hi, 0)) for every non-NaN input, with one VALU
+// instruction per pair for the ReLU instead of two - the fused tower kernels are VALU-issue-bound in their epilogues (round 3: the
+// res2 stage kernel took 32.6 k cycles per tile with every load and MFMA removed).
+__device__ __forceinline__ uint32_t relu2_bf16(float lo, float hi) {
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    union { uint32_t u; s16x2_t v; } x;
+    x.u = pack2_bf16(lo, hi);
+    const s16x2_t z = {0, 0};
+    x.v = __builtin_elementwise_max(x.v, z);
+    return x.u;
+}
+
+// the same with the ReLU as a run-time, wave-uniform flag and no branch: max against INT16_MIN is the identity
+__device__ __forceinline__ uint32_t act2_bf16(float lo, float hi, bool relu) {
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    union { uint32_t u; s16x2_t v; } x;
+    x.u = pack2_bf16(lo, hi);
+    const short f = relu ? (short)0 : (short)-32768;
+    const s16x2_t z = {f, f};
+    x.v = __builtin_elementwise_max(x.v, z);
+    return x.u;
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float load(const float* p) { return *p; }

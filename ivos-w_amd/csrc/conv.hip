@@ -66,9 +66,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
             uint32_t pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float a = v[2 * q], b = v[2 * q + 1];
-                if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-                pk[q] = pack2_bf16(a, b);
+                pk[q] = act2_bf16(v[2 * q], v[2 * q + 1], p.relu != 0);
             }
             if (p.nt & 1) {
                 u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};
@@ -813,9 +811,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
         uint32_t pk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float a = v[2 * k], bq = v[2 * k + 1];
-            if (p.relu) { a = fmaxf(a, 0.f); bq = fmaxf(bq, 0.f); }
-            pk[k] = pack2_bf16(a, bq);
+            pk[k] = act2_bf16(v[2 * k], v[2 * k + 1], p.relu != 0);
         }
         if (p.nt & 4) {                                       // bit 2 (off by default: measured slightly worse for this kernel)
             u32x4 ov = {pk[0], pk[1], pk[2], pk[3]};

@@ -105,18 +105,6 @@ struct WC { uint4 w[8]; float4 b[4]; };              // phase C: one channel til
 struct WD { uint4 w[8]; float4 b[4]; };              // phase D: ring of one output-channel tile (K = 256: 16 k-steps) + bias
 __device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
 
-// ReLU AFTER the bf16 conversion, on the packed pair, as ONE integer instruction (v_pk_max_i16 against 0: a negative bf16 is a
-// negative int16, -0 becomes +0): the same bits as cvt(max(v, 0)) for every finite v, a quarter of the VALU instructions — this
-// kernel is VALU-issue-bound (first ablation: 32.6 k cycles per tile with every load and MFMA removed).
-__device__ __forceinline__ unsigned relu2_bf16(float lo, float hi) {
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    union { unsigned u; s16x2 v; } x;
-    x.u = pack2_bf16(lo, hi);
-    const s16x2 z = {0, 0};
-    x.v = __builtin_elementwise_max(x.v, z);
-    return x.u;
-}
-
 template <int DBG>
 __device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c) {
     if constexpr (DBG & 4) {

@@ -72,6 +72,19 @@ class DAVIS2017AgentTrain(torch.utils.data.Dataset):
                  reward_step=soa["reward_step"][i], reward_done=soa["reward_done"][i], done=soa["done"][i])
             for i in range(npool)]
 
+    @classmethod
+    def from_soa(cls, soa, transform=None):
+        """The dataset over an in-memory SoA (the dict parse_rows / synth.replay_transitions produce) instead of memory_pool.csv:
+        the same per-sample dicts, hence the same collated batches."""
+        self = object.__new__(cls)
+        self.transform, self.soa, self.frame, self.seq_list = transform, soa, None, None
+        self.samples_list = [
+            dict(action=soa["action"][i], old_state_iou=soa["old_state_iou"][i][None], new_state_iou=soa["new_state_iou"][i][None],
+                 annotated_frames=soa["annotated_frames"][i][None], next_annotated_frames=soa["next_annotated_frames"][i][None],
+                 reward_step=soa["reward_step"][i], reward_done=soa["reward_done"][i], done=soa["done"][i])
+            for i in range(len(soa["action"]))]
+        return self
+
     def __len__(self):
         return len(self.samples_list)
 

@@ -53,6 +53,7 @@ def _attr(d):
 # the keys the loop reads (the reference keeps them in configs/config.yaml); values are that file's defaults
 DEFAULTS = dict(
     seed=0, gpu_id=0, phase="eval", setting="wild", method="ours", num_epochs=1, dataset="davis", ckpt_dir="weights",
+    vos_adapter="",                    # module on PYTHONPATH that wraps the VOS backbone for the real stack (default ivosw_vos_<backbone>)
     synthetic=-1,                      # -1 auto (synthetic when the real stack is missing), 0 real stack only, 1 synthetic
     precision="bf16",                  # AssessNet mode: bf16 throughput / fp32 parity
     report_save_dir="results",
@@ -108,15 +109,31 @@ def parse_cli(argv, **overrides):
 
 
 # ------------------------------------------------------------------------------------------ the real stack, or a clear refusal
-REAL_STACK = {"MANet": ("davisinteractive", "cv2", "networks.deeplab"), "ATNet": ("davisinteractive", "cv2", "networks.atnet"),
-              "IPN": ("davisinteractive", "cv2", "model")}
+# What eval_agent_{manet,atnet,ipn}.py need besides this build: the davisinteractive package (session, scribble robot, Davis index),
+# cv2 (frame decoding), the DAVIS frames, and the VOS backbone.  The backbone and its glue are third-party clones the reference
+# keeps outside its own tree (README.md:35-41; SURVEY section 2 marks them OUT OF SCOPE): they enter through ONE small adapter module the
+# caller puts on PYTHONPATH — ``cfg.vos_adapter`` (default ``ivosw_vos_<backbone>``) exposing
+#
+#     build(cfg, device) -> adapter
+#     adapter.start_sequence(sequence, n_frame, n_objects, h, w)          once per (sequence, scribble) sample
+#     adapter.segment(sequence, scribbles, annotated_frame, first_scribble, n_interaction)
+#         -> (labels [n,H,W] integer label maps, all_P [n,O+1,H,W] float32 probabilities on the device)
+#
+# i.e. exactly what the reference's loop computes between "interaction initial" and "frame recommendation"
+# (eval_agent_manet.py:321-396).  For MANet, ``ivos_w_amd.utils.utils_manet.get_results`` is the drop-in for the reference's
+# get_results inside such an adapter.
+REAL_STACK = ("davisinteractive", "cv2")
+
+
+def adapter_module_name(backbone, cfg):
+    return str(cfg.get("vos_adapter") or f"ivosw_vos_{backbone.lower()}")
 
 
 def missing_real_stack(backbone, cfg):
     missing = []
-    for mod in REAL_STACK[backbone]:
+    for mod in REAL_STACK + (adapter_module_name(backbone, cfg),):
         try:
-            if importlib.util.find_spec(mod) is None:
+            if mod not in sys.modules and importlib.util.find_spec(mod) is None:
                 missing.append(f"python module {mod}")
         except (ImportError, ValueError):
             missing.append(f"python module {mod}")
@@ -127,7 +144,8 @@ def missing_real_stack(backbone, cfg):
 
 
 def choose_backend(backbone, cfg):
-    """-> True for the synthetic back end.  ``synthetic=0`` with a missing stack stops with the list of what is missing."""
+    """-> True for the synthetic back end, False for the real stack (davisinteractive session + the caller's VOS adapter).
+    ``synthetic=0`` with a missing stack stops with the list of what is missing."""
     missing = missing_real_stack(backbone, cfg)
     if cfg.synthetic == 1 or (cfg.synthetic == -1 and missing):
         if missing and cfg.synthetic == -1:
@@ -136,9 +154,7 @@ def choose_backend(backbone, cfg):
         return True
     if missing:
         raise SystemExit(f"[ivos-w] synthetic=0 but the {backbone} stack is incomplete: " + "; ".join(missing))
-    raise SystemExit(f"[ivos-w] the {backbone} stack is importable, but its adapter (external clone) is outside this build's scope "
-                     "(SURVEY §8 / DESIGN §7): swap models.agent / models.assessment into the reference's own entry script as "
-                     "INTEGRATION.md shows, or run with synthetic=1.")
+    return False
 
 
 # ------------------------------------------------------------------------------------------ synthetic data + session
@@ -310,7 +326,8 @@ def run_eval(cfg, backbone="MANet"):
     if not torch.cuda.is_available():
         raise SystemExit("[ivos-w] the hot path needs an MI355X (no CPU fallback)")
     device = torch.device(f"cuda:{cfg.gpu_id}")
-    choose_backend(backbone, cfg)
+    if not choose_backend(backbone, cfg):
+        return run_eval_real(cfg, backbone, device)
     misc.set_random_seed(int(cfg.seed))
     davis = SyntheticDavis(cfg, device)
     needs_assess = cfg.setting == "wild" and cfg.method in ("ours", "worst")
@@ -366,6 +383,93 @@ def run_eval(cfg, backbone="MANet"):
     print(f"# global_summary: auc:{auc * 100:.4f}  recommend_frame avg {rec_time.avg * 1e3:.2f} ms  frame-cache uploads "
           f"{utils_agent.frame_cache.uploads}\n# {metric}: " + " ".join(f"{v * 100:.2f}" for v in curve))
     summary["backend"] = "synthetic"
+    summary["report_dir"] = report_dir
+    return summary
+
+
+# ------------------------------------------------------------------------------------------ eval_agent_*  (real stack)
+def run_eval_real(cfg, backbone, device):
+    """The loop of eval_agent_manet.py:246-480 on the REAL stack: davisinteractive's DavisInteractiveSession and scribble robot, the
+    DAVIS frames from disk, the caller's VOS adapter for the segmentation, and this build's hot path for everything the reference
+    owns in that loop: ``sequence_metric`` (J / F), ``recommend_frame`` (AssessNet + agent), the checkpoint loaders.  Writes
+    <report_save_dir>/<backbone>/<setting>/<dataset>/<method>/summary.json like the reference (eval_agent_manet.py:470-480)."""
+    import cv2
+    from davisinteractive import utils as interactive_utils
+    from davisinteractive.dataset import Davis
+    from davisinteractive.session import DavisInteractiveSession
+    from .utils import misc, utils_agent
+    adapter_mod = importlib.import_module(adapter_module_name(backbone, cfg))
+    misc.set_random_seed(int(cfg.seed))
+    root = cfg.data.root_dir_davis
+    needs_assess = cfg.setting == "wild" and cfg.method in ("ours", "worst")
+    agent, assess_net = build_hot_path(cfg, device, needs_assess)
+    agent.set_eval()
+    vos = adapter_mod.build(cfg, device)
+    metric = cfg.davis_interactive.metric
+    max_nb = int(cfg.eval_max_nb_interactions)
+    report_dir = os.path.join(cfg.report_save_dir, backbone, cfg.setting, cfg.dataset, cfg.method)
+    os.makedirs(report_dir, exist_ok=True)
+    davis = Davis(root)
+    seen_seq, frames_of = {}, {}
+    rec_time, corr_all, final_q = misc.AverageMeter(), misc.AverageMeter(), misc.AverageMeter()
+    with DavisInteractiveSession(host="localhost", davis_root=root, subset=cfg.data.subset, metric_to_optimize=metric,
+                                 max_nb_interactions=max_nb, max_time=int(cfg.davis_interactive.max_time_per_interaction) or None,
+                                 report_save_dir=report_dir) as sess:
+        while sess.next():
+            sequence, scribbles, first_scribble = sess.get_scribbles(only_last=True)
+            annotated = interactive_utils.scribbles.annotated_frames(scribbles)
+            if first_scribble:
+                n_objects = Davis.dataset[sequence]["num_objects"]
+                gt_masks = davis.load_annotations(sequence)
+                assert len(annotated) > 0
+                next_frame = first_frame = annotated[0]
+                seen_seq[sequence] = seen_seq.get(sequence, 0) + 1
+                if sequence not in frames_of:                  # decoded once per sequence: also the key of the device frame cache
+                    jdir = os.path.join(root, "JPEGImages", "480p", sequence)
+                    frames_of[sequence] = torch.from_numpy(np.ascontiguousarray(np.stack(
+                        [np.asarray(cv2.imread(os.path.join(jdir, f)), dtype=np.float32)[:, :, [2, 1, 0]] / 255. for f in sorted(os.listdir(jdir))],
+                        0).transpose(0, 3, 1, 2)))
+                all_F = frames_of[sequence]
+                n_frame = len(scribbles["scribbles"])
+                h, w = int(all_F.shape[2]), int(all_F.shape[3])
+                prev_frames = None if cfg.davis_interactive.allow_repeat > 0 else [next_frame]
+                annotated_list = [next_frame]
+                quality_pred = np.zeros(n_frame) if needs_assess else None
+                vos.start_sequence(sequence, n_frame, n_objects, h, w)
+                n_interaction = 1
+            else:
+                annotated_list.append(next_frame)
+                n_interaction += 1
+            scribbles["annotated_frame"] = next_frame
+            with torch.no_grad():
+                labels, all_P = vos.segment(sequence, scribbles, next_frame, first_scribble, n_interaction)
+            new_masks = labels.cpu().numpy() if torch.is_tensor(labels) else np.asarray(labels)
+            quality = misc.sequence_metric(metric, gt_masks, new_masks, n_objects)
+            tic = time.time()
+            next_frame = int(utils_agent.recommend_frame(
+                cfg, assess_net, agent, device, n_frame=n_frame, n_objects=n_objects, all_F=all_F, all_P=all_P, new_masks_quality=quality,
+                prev_frames=prev_frames, annotated_frames_list=copy.deepcopy(annotated_list), mask_quality=quality_pred,
+                first_frame=first_frame, max_nb_interactions=max_nb))
+            if prev_frames is not None:
+                prev_frames.append(next_frame)
+            rec_time.update(time.time() - tic)
+            sess.submit_masks(new_masks, next_scribble_frame_candidates=[next_frame])
+            corr = float(np.corrcoef([quality, quality_pred])[0, 1]) if quality_pred is not None else float("nan")
+            corr_all.update(0.0 if np.isnan(corr) else corr)
+            print(f"avg_{metric}: {quality.mean() * 100:.2f} rec_time:{rec_time.val:.2f} next_frame: {next_frame:2d} "
+                  f"[{int((quality < quality[next_frame]).sum()) + 1:2d}/{n_frame:2d}] corr: {corr:.2f} ({corr_all.avg:.2f}) "
+                  f"seq: {sequence}_{seen_seq[sequence]} [{n_interaction:2d}/{max_nb:2d}]")
+            if n_interaction == max_nb:
+                final_q.update(float(quality.mean()) * 100)
+        gs = sess.get_global_summary()
+    curve = list(gs["curve"][metric][:-1])
+    auc = float(np.trapz(curve) / (len(curve) - 1)) if len(curve) > 1 else float(curve[0])
+    summary = {"auc": auc, "curve": {metric: curve}}
+    with open(os.path.join(report_dir, "summary.json"), "w") as fp:
+        json.dump(summary, fp)
+    print(f"# final avg {metric}: {final_q.avg:.4f}  final avg corr: {corr_all.avg:.4f}\n# global_summary: auc:{auc * 100:.4f}\n# {metric}: "
+          + " ".join(f"{v * 100:.2f}" for v in curve))
+    summary["backend"] = "real"
     summary["report_dir"] = report_dir
     return summary
 
@@ -476,7 +580,10 @@ def run_train(cfg):
             sys.stdout = open(os.devnull, "w")
     else:
         device = torch.device(f"cuda:{cfg.gpu_id}")
-    choose_backend("ATNet", cfg)                                       # the reference trains against ATNet
+    if not choose_backend("ATNet", cfg):                               # the reference trains against ATNet
+        raise SystemExit("[ivos-w] train_agent.py drives the synthetic session only: training against the real ATNet clone needs the "
+                         "reference's run_VOS_singleiact glue (utils/utils_atnet.py, out of scope - SURVEY section 2); evaluate a trained "
+                         "agent on the real stack with eval_agent_*.py synthetic=0, or run with synthetic=1.")
     cfg.data.subset = cfg.data.get("subset", "train")
     misc.set_random_seed(2019)
     davis = SyntheticDavis(cfg, device)

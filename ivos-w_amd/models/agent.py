@@ -353,6 +353,7 @@ class CapturedDqnStep:
         if fused:
             opt.dev_state()
         self._keys = (pn.flat.data_ptr(), tn.flat.data_ptr(), pn.flat_grad.data_ptr())
+        self._hyper = self._hyper_now()          # lr / betas / eps / weight decay / clamp / grad_scale / gamma are baked into the graph
         torch.cuda.synchronize(dev)
         with L.Graph.capture(dev) as g:
           for _ in range(self.steps):
@@ -375,11 +376,19 @@ class CapturedDqnStep:
         self.graph = g
         self.kernel_nodes = g.kernel_nodes
 
+    def _hyper_now(self):
+        g = self.agent.optimizer.param_groups[0]
+        return (float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"]), float(g["clamp"]),
+                float(self.agent.optimizer.grad_scale), float(self.agent.GAMMA))
+
     def launch(self):
         """Enqueue one step on the current stream; ``self.loss`` holds the device loss afterwards."""
         a = self.agent
         if self._keys != (a.policy_net.flat.data_ptr(), a.target_net.flat.data_ptr(), a.policy_net.flat_grad.data_ptr()):
             raise RuntimeError("the parameter arenas moved (.to() / re-pack) after capture: build a new CapturedDqnStep")
+        if self._hyper != self._hyper_now():
+            raise RuntimeError("a hyper-parameter (lr / betas / eps / weight_decay / clamp / grad_scale / gamma) changed after capture: "
+                               "the graph replays the captured values - build a new CapturedDqnStep")
         if self.fused:
             a.optimizer.dev_state()              # resync if an eager step ran in between
         self.graph.launch()

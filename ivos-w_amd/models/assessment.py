@@ -13,6 +13,7 @@ needed and nothing is downloaded.  ``precision='fp32'`` (default) is the parity 
 Inference only (eval-mode BatchNorm): AssessNet training is outside the hot path.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -117,7 +118,12 @@ class AssessNet(nn.Module):
         # state_dict on every call cost a comparable amount of host time.  The first and last tensors stand guard
         # against in-place edits that bypass the counter.
         w0, w1 = self.Encoder.conv1.weight, self.fc1.weight
-        return (self.precision, self._wver, str(w1.device), w0.data_ptr(), w0._version, w1.data_ptr(), w1._version)
+        key = (self.precision, self._wver, str(w1.device), w0.data_ptr(), w0._version, w1.data_ptr(), w1._version)
+        if os.environ.get("IVOSW_WEIGHTS_KEY", "") == "full":
+            # debug / safety switch: walk every tensor, so an in-place edit of ANY parameter or BN buffer that bypassed
+            # load_state_dict / .to() / invalidate_packed() re-packs the weights (the O(1) key watches two tensors and a counter)
+            key += tuple((t.data_ptr(), t._version) for t in self.state_dict().values())
+        return key
 
     def _ensure_packed(self):
         key = self._weights_key()

@@ -80,26 +80,30 @@ def _annotation_counts(n, annotated_frames_list):
 class _FrameCache:
     """The video of the current sequence, resident on the GPU across interactions.  The reference uploads all_F (and all_P)
     on EVERY interaction (utils/utils_agent.py:114-115: 100 frames x 480p fp32 = 0.5 GB, ~10 ms of PCIe per call); the entry
-    scripts build all_F once per sequence (eval_agent_manet.py:297-300), so its identity is a sound cache key."""
+    scripts build all_F once per sequence (eval_agent_manet.py:297-300), so its identity is a sound cache key.  One entry: the
+    previous sequence's host frames (~0.5 GB) stay alive until the next sequence replaces them, or ``clear_frame_cache()``."""
 
     def __init__(self):
-        self.key, self.frames, self.uploads, self.hits = None, None, 0, 0
+        self.key, self.src, self.frames, self.uploads, self.hits = None, None, None, 0, 0
 
     def get(self, all_F, device):
         device = torch.device(device)
         if all_F.is_cuda:
             return all_F if all_F.device == device else all_F.to(device)
+        # The cache holds a STRONG reference to the host tensor and compares identity: while the entry is alive the tensor cannot be
+        # freed, so the allocator cannot hand its address to the next sequence's frames (same shape, same version counter) and make
+        # a stale entry look current.  (data_ptr stays in the key for a tensor object whose storage was swapped with .set_() / .data.)
         key = (all_F.data_ptr(), tuple(all_F.shape), all_F.dtype, all_F._version, str(device))
-        if key != self.key:
+        if self.src is not all_F or key != self.key:
             self.frames = all_F.to(device=device, dtype=torch.float32).contiguous()
-            self.key = key
+            self.key, self.src = key, all_F
             self.uploads += 1
         else:
             self.hits += 1
         return self.frames
 
     def clear(self):
-        self.key, self.frames = None, None
+        self.key, self.src, self.frames = None, None, None
 
 
 frame_cache = _FrameCache()

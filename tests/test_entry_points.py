@@ -29,7 +29,7 @@ def test_missing_real_stack_is_reported_not_faked(capsys):
     c = entry.parse_cli(["with", "synthetic=0"])
     with pytest.raises(SystemExit) as e:
         entry.choose_backend("MANet", c)
-    assert "davisinteractive" in str(e.value) and "DAVIS frames" in str(e.value)
+    assert "davisinteractive" in str(e.value) and "DAVIS frames" in str(e.value) and "ivosw_vos_manet" in str(e.value)
     assert entry.choose_backend("MANet", entry.parse_cli([])) is True           # auto: falls back, and says so
     assert "SYNTHETIC" in capsys.readouterr().out
 
@@ -83,3 +83,105 @@ def test_eval_and_train_loops_on_the_synthetic_back_end(tmp_path):
         if method == "ours":
             assert "frame-cache uploads 2" in r.stdout                              # one upload per sequence, not per interaction
     print(aucs)
+
+
+def _install_real_stack_doubles(monkeypatch, tmp_path, cfg, device):
+    """Stand-ins for the three things the real-stack branch imports from OUTSIDE this build — davisinteractive (session, Davis index,
+    scribble helpers), cv2.imread, and the caller's VOS adapter module — plus a DAVIS directory tree with the frames on disk.  The
+    doubles are built over the synthetic videos, so the run is deterministic and its J&F curve is a real measurement."""
+    import types
+    davis = entry.SyntheticDavis(cfg, device)
+    root = tmp_path / "DAVIS"
+    for seq in davis.dataset:
+        d = root / "JPEGImages" / "480p" / seq
+        d.mkdir(parents=True)
+        F = davis.load_frames(seq)                                            # [n,3,H,W] RGB in [0,1]
+        for i in range(F.shape[0]):
+            bgr = (F[i].permute(1, 2, 0).numpy()[:, :, ::-1] * 255.0).round().astype(np.uint8)
+            with open(d / f"{i:05d}.jpg", "wb") as fh:                        # (a .npy payload under the JPEG name: the cv2 double reads it)
+                np.save(fh, bgr)
+    cfg.data.root_dir_davis = str(root)
+
+    class Davis:
+        dataset = davis.dataset
+        sets = {"val": list(davis.dataset)}
+
+        def __init__(self, davis_root=None):
+            self.davis_root = davis_root
+
+        def load_annotations(self, sequence):
+            return davis.load_annotations(sequence).cpu().numpy()
+
+    class DavisInteractiveSession(entry.SyntheticSession):
+        def __init__(self, host=None, davis_root=None, subset="val", metric_to_optimize="J_AND_F", max_nb_interactions=8, max_time=None,
+                     report_save_dir=None):
+            davis.sets[subset] = list(davis.dataset)
+            super().__init__(davis, subset, metric_to_optimize, max_nb_interactions, report_save_dir, seed=3)
+
+    di = types.ModuleType("davisinteractive")
+    di.session = types.ModuleType("davisinteractive.session")
+    di.session.DavisInteractiveSession = DavisInteractiveSession
+    di.dataset = types.ModuleType("davisinteractive.dataset")
+    di.dataset.Davis = Davis
+    di.utils = types.ModuleType("davisinteractive.utils")
+    di.utils.scribbles = types.ModuleType("davisinteractive.utils.scribbles")
+    di.utils.scribbles.annotated_frames = lambda scr: [i for i, s in enumerate(scr["scribbles"]) if s]
+    cv2 = types.ModuleType("cv2")
+    cv2.imread = lambda path: np.load(path)
+    calls = dict(start=0, segment=0)
+
+    class Adapter:
+        def __init__(self, cfg_, device_):
+            from ivos_w_amd.utils import utils_manet
+            self.device, self.um, self.vos = device_, utils_manet, entry.StandInVOS(device_, seed=0)
+
+        def start_sequence(self, sequence, n_frame, n_objects, h, w):
+            calls["start"] += 1
+            self.n_objects, self.annotated = n_objects, []
+            self.store = self.um.ProbStore(n_frame, n_objects + 1, h, w, self.device)
+
+        def segment(self, sequence, scribbles, annotated_frame, first_scribble, n_interaction):
+            calls["segment"] += 1
+            assert scribbles["annotated_frame"] == annotated_frame and scribbles["scribbles"][annotated_frame]
+            self.annotated.append(annotated_frame)
+            gt = davis.load_annotations(sequence)
+            self.um.seg_epilogue(self.vos.logits(gt, self.n_objects, self.annotated), gt.shape[1], gt.shape[2], self.store, 0)
+            return self.store.labels_u8, self.store.all_P
+
+    ad = types.ModuleType("ivosw_vos_manet")
+    ad.build = lambda cfg_, device_: Adapter(cfg_, device_)
+    for name, mod in (("davisinteractive", di), ("davisinteractive.session", di.session), ("davisinteractive.dataset", di.dataset),
+                      ("davisinteractive.utils", di.utils), ("davisinteractive.utils.scribbles", di.utils.scribbles), ("cv2", cv2),
+                      ("ivosw_vos_manet", ad)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    return davis, calls
+
+
+@pytest.mark.gpu
+def test_real_stack_branch_runs_end_to_end_under_test_doubles(tmp_path, monkeypatch, capsys):
+    """``synthetic=0``: eval_agent_manet.py's loop on the REAL-stack branch (entry.run_eval_real) — DavisInteractiveSession, Davis,
+    cv2 and the caller's VOS adapter are test doubles injected as modules, the DAVIS frames are read from a directory tree, and
+    everything the reference owns in that loop is this build's hot path (frame decode -> frame cache, sequence_metric on the GPU,
+    recommend_frame = AssessNet + agent).  Writes summary.json; the curve improves with the interactions."""
+    dev = torch.device("cuda:0")
+    common = ["synthetic=0", "setting=wild", "method=ours", "synth.n_sequences=2", "synth.n_frames=20", "synth.height=120", "synth.width=216",
+              f"ckpt_dir={tmp_path}/weights", f"report_save_dir={tmp_path}/results", "eval_max_nb_interactions=4"]
+    cfg = entry.parse_cli(["with"] + common)
+    davis, calls = _install_real_stack_doubles(monkeypatch, tmp_path, cfg, dev)
+    assert entry.missing_real_stack("MANet", cfg) == [] and entry.choose_backend("MANet", cfg) is False
+    out = entry.run_eval(cfg, "MANet")
+    text = capsys.readouterr().out
+    assert out["backend"] == "real" and "SYNTHETIC" not in text
+    summary = json.load(open(os.path.join(out["report_dir"], "summary.json")))
+    curve = summary["curve"]["J_AND_F"]
+    assert len(curve) == 4 and all(0.0 < v <= 1.0 for v in curve) and curve[-1] > curve[0]
+    assert abs(summary["auc"] - np.trapz(curve) / 3) < 1e-9
+    assert calls["start"] == len(davis.dataset) and calls["segment"] == 4 * len(davis.dataset)
+    assert out["report_dir"].endswith(os.path.join("MANet", "wild", "davis", "ours"))
+    # the other methods of the reference's table run on the same branch
+    for method in ("worst", "random"):
+        c2 = entry.parse_cli(["with"] + common + [f"method={method}"])
+        c2.data.root_dir_davis = cfg.data.root_dir_davis
+        o2 = entry.run_eval(c2, "MANet")
+        assert o2["backend"] == "real" and len(o2["curve"]["J_AND_F"]) == 4
+    capsys.readouterr()

@@ -417,14 +417,7 @@ def test_train_phase_epsilon_greedy_vs_reference_golden(dev, golden_dir):
 def _synthetic_replay_dataset(n=300, T=25, seed=3):
     """A DAVIS2017AgentTrain without the CSV round trip: the same per-sample dicts (datasets/agent_dataset.py) over a synthetic SoA."""
     from ivos_w_amd.datasets.agent_dataset import DAVIS2017AgentTrain
-    soa = synth.replay_transitions(n=n, T=T, seed=seed)
-    ds = object.__new__(DAVIS2017AgentTrain)
-    ds.transform, ds.soa = None, soa
-    ds.samples_list = [
-        dict(action=soa["action"][i], old_state_iou=soa["old_state_iou"][i][None], new_state_iou=soa["new_state_iou"][i][None],
-             annotated_frames=soa["annotated_frames"][i][None], next_annotated_frames=soa["next_annotated_frames"][i][None],
-             reward_step=soa["reward_step"][i], reward_done=soa["reward_done"][i], done=soa["done"][i]) for i in range(n)]
-    return ds
+    return DAVIS2017AgentTrain.from_soa(synth.replay_transitions(n=n, T=T, seed=seed))
 
 
 def test_agent_business_device_update_loop_equals_the_per_batch_loop(dev, capsys, monkeypatch):

@@ -118,7 +118,7 @@ def test_world2_product_path_matches_single_process_full_batch(mode):
     assert np.array_equal(res[0][-1][2], res[0][-1][1]) == bool(torch.equal(agent.target_net.flat, agent.policy_net.flat))
 
 
-@pytest.mark.parametrize("variant", ["default", "graph_no_p2p"])
+@pytest.mark.parametrize("variant", ["default", "graph_no_p2p", "strong"])
 def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     """bench.py's N > 1 branch exactly as the driver launches it (torch.distributed.run, one process per rank, barrier + max over
     ranks, rank 0 prints the line) — on this one-GPU box with both ranks on cuda:0 and the gloo rendezvous (two ranks cannot
@@ -138,6 +138,9 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     if variant == "graph_no_p2p":
         env["IVOSW_P2P"] = "0"
         extra = ["--dqn-dp", "graph"]
+    if variant == "strong":                                  # 16 frames IN TOTAL, 8 per rank ("256 total (strong)")
+        env["IVOSW_P2P"] = "0"
+        extra = ["--scaling", "strong"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--min-warm-s", "0",
            "--batch", "16", "--dqn-steps", "30", "--backend", "gloo", "--no-fp32"] + extra
@@ -146,9 +149,13 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["value"] > 0 and d["checked"] is True
+    assert d["n_gpus"] == 2 and d["scaling"] == ("strong" if variant == "strong" else "weak") and d["steps"] == 3 and d["value"] > 0 and d["checked"] is True
     assert d["config"]["parallelism"] == "frames sharded x2" and "cpu_baseline" not in d
+    assert (d["config"]["total_batch"], d["config"]["batch_per_gpu"]) == ((16, 8) if variant == "strong" else (32, 16))
+    assert abs(d["value"] - d["config"]["total_batch"] * 3 / (d["ms_per_step"] * 3e-3)) < 0.02 * d["value"]       # value = frames of ALL ranks / time
     assert d["dqn"]["value"] > 0 and "all-reduce" in d["dqn"]["collective"]
+    if variant == "strong":
+        return
     if variant == "default":
         legs = d["dqn"]["collectives"]                       # both collective paths are timed; the faster validated one is dqn.value
         assert set(legs) == {"backend", "p2p"} and all(v.get("us_per_step", 0) > 0 for v in legs.values()), legs
