@@ -374,7 +374,7 @@ def bench_assess(args, rank, world, dev, dist):
             "streams": 2 if split else 1,
             "timing": "one HIP-event pair per forward pass around the tower's launches, inside the timed region (family time includes its own launch gaps)"
                       + ("; the batch runs as two halves on two streams: family time = latest end - earliest start of the halves' tower spans" if split else "")}
-    if rank == 0 and args.precision == "bf16":
+    if rank == 0 and args.precision == "bf16" and not args.no_clock_probe:
         # the clock / power the kernels ran at: frac stays against the 2.5 PFLOP/s of a 2.4 GHz chip;
         # frac_at_measured_clock is the same achieved rate against the MFMA peak AT THE MEASURED shader clock, beside it
         try:
@@ -803,6 +803,7 @@ def main():
     ap.add_argument("--dqn-block", type=int, default=8, help="N = 1: training steps per hipGraphLaunch when no target-sync coin of the block fires (1 = one graph launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layer-report", default="", help="write a per-conv-layer timing table (HIP events) to this file")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the 15 extra forward passes that measure roofline.sclk_mhz / power_w (profiling runs count passes)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not re-run the forward under rocprofv3 --pmc for roofline.traffic (the committed PMC summary is quoted instead)")
     ap.add_argument("--tower-only", action="store_true", help="(internal: the rocprofv3 --pmc sub-runs) build the inputs, run warmup + steps forward passes, print nothing else")
     args = ap.parse_args()
