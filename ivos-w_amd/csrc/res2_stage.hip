@@ -44,6 +44,11 @@
 namespace ivosw {
 
 namespace {
+#ifndef R2_DEPTH0                                    // k-steps of lead of the 3x3's pixel-fragment reads per block: 2 / 1 / 2 measured the same as
+#define R2_DEPTH0 1                                  // 1 / 1 / 1 (B0 11 437 vs 11 387 cycles, B2 5 398 vs 5 788): the loops do not wait for LDS latency
+#define R2_DEPTH1 1
+#define R2_DEPTH2 1
+#endif
 constexpr int R2_LDS = 163840;
 constexpr int T1R = 144;                             // bytes per padded t1 raster row
 constexpr int P_OFF = 0, T1A_OFF = 39936, SB0_OFF = 84288, PD_OFF = 0, T2A_OFF = 30720, Y0_OFF = 63488, T1B_OFF = 129024;
@@ -116,7 +121,7 @@ __device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c) {
 // ---------------------------------------------------------------- phase B: 3x3 on a padded raster, NPT pixel tiles of slots
 // t1 raster of width SRCW at T1_OFF -> t2 [slot][128 B swizzled] at T2_OFF; partial sums through SB_OFF.  `ahead` runs between
 // the k-loop and the exchange: the caller requests the next phase's weights there.
-template <int NPT, int SRCW, int DBG, int PER, typename FO, typename F>
+template <int NPT, int SRCW, int DBG, int PER, int DEPTH, typename FO, typename F>
 __device__ __forceinline__ void phase_b(unsigned char* lds, unsigned lds_base, int T1_OFF, int T2_OFF, int SB_OFF, WB& wb, int wave,
                                         int lane, FO&& own, F&& ahead) {
     constexpr int NT = NPT / 2, OFS = (SRCW - 16) / 2 - 1;
@@ -136,23 +141,26 @@ __device__ __forceinline__ void phase_b(unsigned char* lds, unsigned lds_base, i
     }
     auto run_half = [&](auto khc) {
         constexpr int K0 = decltype(khc)::value * 18;
-        u32x4 pf[2][NT];
-        auto rd = [&](auto kc, int buf) {
-            constexpr int kstep = K0 + decltype(kc)::value;
+        // pixel fragments DEPTH k-steps ahead of the MFMAs that use them (a ring of DEPTH + 1 sets): with two or three MFMAs per
+        // k-step and two waves per SIMD, one step of lead (~128 - 256 cycles) is about the LDS round trip under eight waves' load
+        u32x4 pf[DEPTH + 1][NT];
+        auto rd = [&](auto kc) {
+            constexpr int kstep = K0 + decltype(kc)::value, buf = decltype(kc)::value % (DEPTH + 1);
             constexpr int tap = kstep >> 2, ks = kstep & 3, toff = (tap / 3) * SRCW + (tap % 3);
 #pragma unroll
             for (int i = 0; i < NT; ++i) pf[buf][i] = lds_read_b128_o<toff * T1R + ks * 32>(rb[i]);
         };
         lgkm<0>();                                   // nothing of the compiler's (LDS or scalar loads) may be outstanding when the counted waits start
-        rd(std::integral_constant<int, 0>{}, 0);
+        static_for<0, DEPTH>([&](auto kc) { rd(kc); });
         static_for<0, 18>([&](auto kc) {
             constexpr int KS = decltype(kc)::value;
-            if constexpr (KS < 17 && !(DBG & 2)) rd(std::integral_constant<int, KS + 1>{}, (KS + 1) & 1);
+            if constexpr (KS + DEPTH < 18 && !(DBG & 2)) rd(std::integral_constant<int, KS + DEPTH>{});
             if constexpr (KS >= 9) static_for<0, PER>([&](auto jc) { ahead(std::integral_constant<int, (KS - 9) * PER + decltype(jc)::value>{}); });
-            if (DBG & 2) { if (KS == 0) lgkm<0>(); } else if (KS < 17) lgkm<NT>(); else lgkm<0>();
+            constexpr int INFLIGHT = (17 - KS < DEPTH ? 17 - KS : DEPTH) * NT;       // reads younger than this step's
+            if (DBG & 2) { if (KS == 0) lgkm<0>(); } else lgkm<INFLIGHT>();
             const u32x4 w = u4(wb.w[KS % 9]);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) acc[i] = mm<DBG>(w, pf[(DBG & 2) ? 0 : (KS & 1)][i], acc[i]);
+            for (int i = 0; i < NT; ++i) acc[i] = mm<DBG>(w, pf[(DBG & 2) ? 0 : (KS % (DEPTH + 1))][i], acc[i]);
             if constexpr (KS < 9) {                  // slot KS is free: fragment 9 + KS of this K half
                 __builtin_amdgcn_sched_barrier(0);
                 own(kc);
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
     // ================================================================ block 0
     using I8 = std::integral_constant<int, 8>;
     using I4 = std::integral_constant<int, 4>;
-    phase_b<8, 22, DBG, 2>(lds, lds_base, T1A_OFF, T2A_OFF, SB0_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[0]); },
+    phase_b<8, 22, DBG, 2, R2_DEPTH0>(lds, lds_base, T1A_OFF, T2A_OFF, SB0_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[0]); },
                            [&](auto n) { ld_wc(n, I8{}, wc[0], p.fc[0], p.bc[0], cc); });
     wait_vmcnt<0>();                                 // this wave's share of PD has landed
     wg_barrier();
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
         stamp(5);
     }
     // ================================================================ block 1
-    phase_b<6, 20, DBG, 1>(lds, lds_base, T1B_OFF, T2B_OFF, SB1_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[1]); },
+    phase_b<6, 20, DBG, 1, R2_DEPTH1>(lds, lds_base, T1B_OFF, T2B_OFF, SB1_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[1]); },
                            [&](auto n) { ld_wc(n, I4{}, wc[0], p.fc[1], p.bc[1], cc); });
     wg_barrier();
     stamp(6);
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
         stamp(8);
     }
     // ================================================================ block 2
-    phase_b<4, 18, DBG, 1>(lds, lds_base, T1C_OFF, T2C_OFF, SB2_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[2]); },
+    phase_b<4, 18, DBG, 1, R2_DEPTH2>(lds, lds_base, T1C_OFF, T2C_OFF, SB2_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[2]); },
                            [&](auto n) { ld_wc(n, I4{}, wc[0], p.fc[2], p.bc[2], cc); });
     wg_barrier();
     stamp(9);

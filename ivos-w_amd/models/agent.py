@@ -377,6 +377,10 @@ class CapturedDqnStep:
         self.kernel_nodes = g.kernel_nodes
 
     def _hyper_now(self):
+        """What the captured launches bake in: gamma always (the loss); the optimizer's values only when clamp + Adam are part of
+        the graph (fused) — the gradient-only graph of the data-parallel step leaves them to the eager update."""
+        if not self.fused:
+            return (float(self.agent.GAMMA),)
         g = self.agent.optimizer.param_groups[0]
         return (float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"]), float(g["clamp"]),
                 float(self.agent.optimizer.grad_scale), float(self.agent.GAMMA))
