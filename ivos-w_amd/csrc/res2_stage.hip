@@ -98,6 +98,32 @@ __device__ __forceinline__ void slot_pos(int s, int& dy, int& dx) {
 }
 __device__ __forceinline__ bool slot_used(int s) { return s < 180 || (s >= 192 && s < 252); }
 
+// The lane's pixel position in pixel tile t (slot t * 32 + lrow).  Core tiles (t < 4) have a closed form; the ring tiles' branchy
+// decoding (slot_pos) is done ONCE per kernel and kept packed in two registers — it used to run ~25 times per wave and tile (every
+// phase that turns slots into raster addresses), ~15 % of the non-MFMA instructions of a kernel that is VALU-issue-bound.
+struct TilePos {
+    unsigned ring[2];                                // tiles 4 | 5 and 6 | 7: (dy + 2) | (dx + 2) << 8 in each half
+    int lrow;
+    __device__ __forceinline__ void init(int lrow_) {
+        lrow = lrow_;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int dy0, dx0, dy1, dx1;
+            slot_pos((4 + 2 * k) * 32 + lrow, dy0, dx0);
+            slot_pos((5 + 2 * k) * 32 + lrow, dy1, dx1);
+            ring[k] = (unsigned)((dy0 + 2) | ((dx0 + 2) << 8)) | ((unsigned)((dy1 + 2) | ((dx1 + 2) << 8)) << 16);
+        }
+    }
+    __device__ __forceinline__ void get(int t, int& dy, int& dx) const {      // t is wave-uniform
+        if (t < 4) {
+            dy = 2 * t + (lrow >> 4); dx = lrow & 15;
+        } else {
+            const unsigned r = (t < 6 ? ring[0] : ring[1]) >> ((t & 1) * 16);
+            dy = (int)(r & 0xff) - 2; dx = (int)((r >> 8) & 0xff) - 2;
+        }
+    }
+};
+
 // Weights and biases of a phase are REQUESTED ONE PHASE AHEAD (plain loads pinned by a scheduling fence: hipcc otherwise sinks
 // them to their first use) — the first timeline of this kernel showed every phase opening with an exposed L2 round trip
 // (~1-2 k cycles of a 3-6 k cycle phase) and the 3x3's three-k-step weight ring stalling on every refill.
@@ -123,7 +149,7 @@ __device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c) {
 // the k-loop and the exchange: the caller requests the next phase's weights there.
 template <int NPT, int SRCW, int DBG, int PER, int DEPTH, typename FO, typename F>
 __device__ __forceinline__ void phase_b(unsigned char* lds, unsigned lds_base, int T1_OFF, int T2_OFF, int SB_OFF, WB& wb, int wave,
-                                        int lane, FO&& own, F&& ahead) {
+                                        int lane, const TilePos& tp, FO&& own, F&& ahead) {
     constexpr int NT = NPT / 2, OFS = (SRCW - 16) / 2 - 1;
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int ct = wave & 1, q = (wave >> 1) & 1, kh = wave >> 2;
@@ -136,7 +162,7 @@ __device__ __forceinline__ void phase_b(unsigned char* lds, unsigned lds_base, i
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         int dy, dx;
-        slot_pos((q + 2 * i) * 32 + lrow, dy, dx);
+        tp.get(q + 2 * i, dy, dx);
         rb[i] = lds_base + T1_OFF + ((dy + OFS) * SRCW + dx + OFS) * T1R + lhalf * 16;
     }
     auto run_half = [&](auto khc) {
@@ -277,8 +303,10 @@ __device__ __forceinline__ void finish_c(const f32x16& a, const unsigned (&res)[
 
 // ---------------------------------------------------------------- phase D k-steps: dacc[i] += w[k] y[tile i], k < NKS
 // y image: slices of 64 channels, NROWS rows each; tiles of a wave are PSTRIDE tiles apart (rows PSTRIDE * 32 apart: same key)
-template <int NKS, int NROWS, int PSTRIDE, int DBG, int PER, typename FO, typename F>
-__device__ __forceinline__ void phase_d_mma(f32x16 (&dacc)[2], bool two, unsigned lds_base, int Y_OFF, WD& wd, int row0, int lane, FO&& own,
+// TWO (second pixel tile or not) is a TEMPLATE parameter: as a run-time flag it put wave-uniform branches inside the counted-wait loop,
+// which neither hipcc's scheduler nor tools/asm_inflight_scan.py (a linear scan) follows well
+template <int NKS, int NROWS, int PSTRIDE, int DBG, int PER, bool two, typename FO, typename F>
+__device__ __forceinline__ void phase_d_mma(f32x16 (&dacc)[2], unsigned lds_base, int Y_OFF, WD& wd, int row0, int lane, FO&& own,
                                             F&& ahead) {
     const int lhalf = lane >> 5;
     const unsigned yrow = lds_base + Y_OFF + row0 * ROWB;
@@ -311,12 +339,12 @@ __device__ __forceinline__ void phase_d_mma(f32x16 (&dacc)[2], bool two, unsigne
 // where a slot's t1 goes in a raster of width RW whose origin sits OFS pixels up-left of the tile origin: LDS byte address of the
 // row (0xffffffff: unused slot) and whether the pixel lies inside the frame (else the 3x3's zero padding is stored)
 template <int RW, int OFS>
-__device__ __forceinline__ void t1_target(int slot, int y0, int x0, unsigned base, unsigned& addr, unsigned& mask) {
+__device__ __forceinline__ void t1_target(const TilePos& tp, int tile, int y0, int x0, unsigned base, unsigned& addr, unsigned& mask) {
     int dy, dx;
-    slot_pos(slot, dy, dx);
+    tp.get(tile, dy, dx);
     const int y = y0 + dy, x = x0 + dx;
     mask = (y >= 0 && y < 64 && x >= 0 && x < 64) ? 0xffffffffu : 0u;
-    addr = slot_used(slot) ? base + ((dy + OFS) * RW + dx + OFS) * T1R : 0xffffffffu;
+    addr = slot_used(tile * 32 + tp.lrow) ? base + ((dy + OFS) * RW + dx + OFS) * T1R : 0xffffffffu;
 }
 // one branch per tile (unused slots), the frame mask as an AND: no per-store predication
 __device__ __forceinline__ void store_t1(const f32x16& d, const float4 (&b)[4], unsigned addr, unsigned mask, int ct, int lhalf) {
@@ -334,15 +362,13 @@ __device__ __forceinline__ void store_t1(const f32x16& d, const float4 (&b)[4], 
 template <bool YS2, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[R2_LDS];
-    // Every kernel argument is copied into a laundered local FIRST.  Under SGPR pressure hipcc otherwise re-reads argument pointers
-    // with s_load INSIDE the MFMA loops; scalar loads share lgkmcnt with the LDS reads and return out of order, so the counted
-    // s_waitcnt lgkmcnt(N) of the fragment pipeline would release before its own reads had landed (the first persistent version
-    // of this kernel computed garbage that way).  Laundered values can only be spilled to VGPR lanes (v_writelane), never reloaded.
-    Res2StageArgs p = kargs;
-    asm volatile("" : "+s"(p.x), "+s"(p.y), "+s"(p.t1out), "+s"(p.fa0), "+s"(p.ba0), "+s"(p.zeros), "+s"(p.ts), "+s"(p.B));
-    asm volatile("" : "+s"(p.fb[0]), "+s"(p.fb[1]), "+s"(p.fb[2]), "+s"(p.bb[0]), "+s"(p.bb[1]), "+s"(p.bb[2]));
-    asm volatile("" : "+s"(p.fc[0]), "+s"(p.fc[1]), "+s"(p.fc[2]), "+s"(p.bc[0]), "+s"(p.bc[1]), "+s"(p.bc[2]));
-    asm volatile("" : "+s"(p.fd[0]), "+s"(p.fd[1]), "+s"(p.fd[2]), "+s"(p.bd[0]), "+s"(p.bd[1]), "+s"(p.bd[2]));
+    // Scalar loads share lgkmcnt with the LDS reads and return out of order, so an s_load INSIDE the MFMA loops would make the counted
+    // s_waitcnt lgkmcnt(N) of the fragment pipeline release before its own reads had landed.  hipcc re-reads kernel arguments that way
+    // under SGPR pressure (the persistent variant of this kernel did, and computed garbage).  In this one-tile-per-workgroup form all
+    // argument loads sit in the prologue; tools/asm_inflight_scan.py fails the build check (tests/test_cabi.py) if one ever appears
+    // behind the first barrier.  (Laundering every argument into SGPR locals also prevents it, but costs 5 %: 64.6 k vs 60.0 k cycles
+    // per tile - the 60 live SGPRs are spilled to VGPR lanes and read back with v_readlane in front of every weight load.)
+    const Res2StageArgs& p = kargs;
     const int tid = threadIdx.x;
     int lane = tid & 63;
     int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -423,6 +449,11 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
     // DMA has landed, and loads placed under a branch make hipcc drain vmcnt(0) at every block boundary)
     const int tile = wslot;
     set_tile(tile);
+    TilePos tp;
+    tp.init(lrow);
+#ifdef R2_SETPRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);    // (experiment) static priority for the second-dispatched half of the workgroup
+#endif
     stamped = 1;
     stamp(0);
     issue_p(tile);
@@ -499,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
     // ================================================================ block 0
     using I8 = std::integral_constant<int, 8>;
     using I4 = std::integral_constant<int, 4>;
-    phase_b<8, 22, DBG, 2, R2_DEPTH0>(lds, lds_base, T1A_OFF, T2A_OFF, SB0_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[0]); },
+    phase_b<8, 22, DBG, 2, R2_DEPTH0>(lds, lds_base, T1A_OFF, T2A_OFF, SB0_OFF, wb, wave, lane, tp, [&](auto k) { own_wb(k, p.fb[0]); },
                            [&](auto n) { ld_wc(n, I8{}, wc[0], p.fc[0], p.bc[0], cc); });
     wait_vmcnt<0>();                                 // this wave's share of PD has landed
     wg_barrier();
@@ -514,8 +545,8 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[i][r] = 0.f;
         unsigned ta[2], tin[2];
-        t1_target<20, 2>(dv * 32 + lrow, y0, x0, lds_base + T1B_OFF, ta[0], tin[0]);
-        t1_target<20, 2>((dv + 4) * 32 + lrow, y0, x0, lds_base + T1B_OFF, ta[1], tin[1]);
+        t1_target<20, 2>(tp, dv, y0, x0, lds_base + T1B_OFF, ta[0], tin[0]);
+        t1_target<20, 2>(tp, dv + 4, y0, x0, lds_base + T1B_OFF, ta[1], tin[1]);
         static_for<0, 2>([&](auto rc_) {
             constexpr int R = decltype(rc_)::value;
             static_for<0, 2>([&](auto hc_) {            // two tile pairs: 4 accumulator tiles + D0's two would not fit beside the residuals
@@ -536,10 +567,10 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
             });
             wg_barrier();                            // y0 K half R is in the image
             if constexpr (R == 0) {
-                phase_d_mma<8, 256, 4, DBG, 2>(dacc, true, lds_base, Y0_OFF, wd, dv * 32 + lrow, lane, none_ahead, [&](auto n) { ld_wc(n, I8{}, wc[1], p.fc[0], p.bc[0], 4 + cc); });
+                phase_d_mma<8, 256, 4, DBG, 2, true>(dacc, lds_base, Y0_OFF, wd, dv * 32 + lrow, lane, none_ahead, [&](auto n) { ld_wc(n, I8{}, wc[1], p.fc[0], p.bc[0], 4 + cc); });
                 wg_barrier();                        // image free for the second half
             } else {
-                phase_d_mma<8, 256, 4, DBG, 2>(dacc, true, lds_base, Y0_OFF, wd, dv * 32 + lrow, lane, none_ahead, [&](auto n) { ld_wb(n, p.fb[1], p.bb[1]); });
+                phase_d_mma<8, 256, 4, DBG, 2, true>(dacc, lds_base, Y0_OFF, wd, dv * 32 + lrow, lane, none_ahead, [&](auto n) { ld_wb(n, p.fb[1], p.bb[1]); });
             }
         });
         stamp(4);
@@ -549,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
         stamp(5);
     }
     // ================================================================ block 1
-    phase_b<6, 20, DBG, 1, R2_DEPTH1>(lds, lds_base, T1B_OFF, T2B_OFF, SB1_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[1]); },
+    phase_b<6, 20, DBG, 1, R2_DEPTH1>(lds, lds_base, T1B_OFF, T2B_OFF, SB1_OFF, wb, wave, lane, tp, [&](auto k) { own_wb(k, p.fb[1]); },
                            [&](auto n) { ld_wc(n, I4{}, wc[0], p.fc[1], p.bc[1], cc); });
     wg_barrier();
     stamp(6);
@@ -583,17 +614,19 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[i][r] = 0.f;
         unsigned ta[2], tin[2];
-        t1_target<18, 1>(dv * 32 + lrow, y0, x0, lds_base + T1C_OFF, ta[0], tin[0]);
-        t1_target<18, 1>((dv + 4) * 32 + lrow, y0, x0, lds_base + T1C_OFF, ta[1], tin[1]);
-        phase_d_mma<16, 192, 4, DBG, 2>(dacc, two, lds_base, Y1_OFF, wd, dv * 32 + lrow, lane, [&](auto k) { own_wd(k, p.fd[1], dct); },
-                                       [&](auto n) { ld_wb(n, p.fb[2], p.bb[2]); });
+        t1_target<18, 1>(tp, dv, y0, x0, lds_base + T1C_OFF, ta[0], tin[0]);
+        t1_target<18, 1>(tp, dv + 4, y0, x0, lds_base + T1C_OFF, ta[1], tin[1]);
+        if (two) phase_d_mma<16, 192, 4, DBG, 2, true>(dacc, lds_base, Y1_OFF, wd, dv * 32 + lrow, lane, [&](auto k) { own_wd(k, p.fd[1], dct); },
+                                                       [&](auto n) { ld_wb(n, p.fb[2], p.bb[2]); });
+        else phase_d_mma<16, 192, 4, DBG, 2, false>(dacc, lds_base, Y1_OFF, wd, dv * 32 + lrow, lane, [&](auto k) { own_wd(k, p.fd[1], dct); },
+                                                    [&](auto n) { ld_wb(n, p.fb[2], p.bb[2]); });
         store_t1(dacc[0], wd.b, ta[0], tin[0], dct, lhalf);
         if (two) store_t1(dacc[1], wd.b, ta[1], tin[1], dct, lhalf);
         wg_barrier();                                // t1_2 complete; y image, t2_1 dead
         stamp(8);
     }
     // ================================================================ block 2
-    phase_b<4, 18, DBG, 1, R2_DEPTH2>(lds, lds_base, T1C_OFF, T2C_OFF, SB2_OFF, wb, wave, lane, [&](auto k) { own_wb(k, p.fb[2]); },
+    phase_b<4, 18, DBG, 1, R2_DEPTH2>(lds, lds_base, T1C_OFF, T2C_OFF, SB2_OFF, wb, wave, lane, tp, [&](auto k) { own_wb(k, p.fb[2]); },
                            [&](auto n) { ld_wc(n, I4{}, wc[0], p.fc[2], p.bc[2], cc); });
     wg_barrier();
     stamp(9);
@@ -620,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[i][r] = 0.f;
-        phase_d_mma<16, 128, 2, DBG, 1>(dacc, true, lds_base, Y2_OFF, wd, d2v * 32 + lrow, lane, [&](auto k) { own_wd(k, p.fd[2], d2ct); }, none_ahead);
+        phase_d_mma<16, 128, 2, DBG, 1, true>(dacc, lds_base, Y2_OFF, wd, d2v * 32 + lrow, lane, [&](auto k) { own_wd(k, p.fd[2], d2ct); }, none_ahead);
         bf16_t* T1O = static_cast<bf16_t*>(p.t1out) + (size_t)b * 64 * 64 * 128;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {

@@ -83,3 +83,23 @@ def test_product_code_never_imports_the_oracle():
                 if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, f)).read(), re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_stage_kernel_isa_has_no_use_of_an_in_flight_asm_ds_read(tmp_path):
+    """res2_stage.hip reads its MFMA fragments with inline-asm ds_reads and counted lgkmcnt waits.  hipcc believes an asm's output is valid
+    at once, so under register pressure it may spill / copy / reuse the destination BEFORE the data has landed (the persistent variant of
+    the kernel computed garbage that way).  Build check: compile the file to gfx950 ISA and let tools/asm_inflight_scan.py look for any
+    instruction that touches the destination of a ds_read still in flight."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this host")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = str(tmp_path / "res2_stage.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-S", "--cuda-device-only",
+                        os.path.join(root, "ivos-w_amd", "csrc", "res2_stage.hip"), "-o", asm], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_inflight_scan.py"), asm], capture_output=True, text=True, timeout=300)
+    assert s.returncode == 0 and "res2_stage_kernel" in s.stdout, s.stdout[-2000:]
