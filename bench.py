@@ -284,9 +284,9 @@ def _read_power_w():
     return None
 
 
-def measure_clock_and_power(step, dev, passes=12):
+def measure_clock_and_power(step, dev, passes=12, spin_us=2500):
     """Shader clock and socket power UNDER the measured load: while `passes` more forward passes run back to back, a one-wave probe
-    kernel on a side stream spins for ~2.5 ms per pass and reports (shader cycles by s_memtime) / (100 MHz wall ticks by
+    kernel on a side stream spins for `spin_us` (~ one pass: the clock differs from kernel to kernel, so the window must cover the pass) and reports (shader cycles by s_memtime) / (100 MHz wall ticks by
     s_memrealtime) -> MHz; the hwmon power node is read from the host between passes.  The probe occupies one wave slot of one CU."""
     lib = L.lib()
     side = torch.cuda.Stream(device=dev)
@@ -296,7 +296,7 @@ def measure_clock_and_power(step, dev, passes=12):
     torch.cuda.synchronize(dev)
     watts = []
     for i in range(passes):
-        L.check(lib.ivosw_clock_probe(out[i].data_ptr(), 2500, ctypes.c_void_p(side.cuda_stream)), "clock_probe")
+        L.check(lib.ivosw_clock_probe(out[i].data_ptr(), int(spin_us), ctypes.c_void_p(side.cuda_stream)), "clock_probe")
         step()
         w = _read_power_w()
         if w is not None:
@@ -305,7 +305,8 @@ def measure_clock_and_power(step, dev, passes=12):
     o = out.cpu().numpy().astype(np.float64)
     mhz = o[:, 0] / np.maximum(o[:, 1], 1.0) * 100.0
     rec = {"sclk_mhz": round(float(np.median(mhz)), 1), "sclk_mhz_min_max": [round(float(mhz.min()), 1), round(float(mhz.max()), 1)],
-           "sclk_source": "s_memtime / s_memrealtime of a one-wave probe kernel running beside 12 back-to-back forward passes (ivosw_clock_probe)",
+           "sclk_source": f"s_memtime / s_memrealtime of a one-wave probe kernel ({int(spin_us)} us windows = one pass each) running beside 12 back-to-back forward passes (ivosw_clock_probe); "
+                          "a PASS AVERAGE: MFMA-dense kernels pull the clock down (res4 / res3 block kernels run at ~1.45 - 1.55 GHz by their own cycle stamps), lighter ones run above it",
            "power_w": round(float(np.mean(watts)), 1) if watts else None,
            "power_source": "amdgpu hwmon power1_average, read between the passes" if watts else "no readable hwmon power node on this box"}
     return rec
@@ -378,7 +379,7 @@ def bench_assess(args, rank, world, dev, dist):
         # the clock / power the kernels ran at: frac stays against the 2.5 PFLOP/s of a 2.4 GHz chip;
         # frac_at_measured_clock is the same achieved rate against the MFMA peak AT THE MEASURED shader clock, beside it
         try:
-            cp = measure_clock_and_power(step, dev)
+            cp = measure_clock_and_power(step, dev, spin_us=max(500, int(dt / args.steps * 1e6 * 0.97)))
             roof.update(cp)
             if cp["sclk_mhz"] > 0:
                 roof["peak_at_measured_clock"] = round(peak * cp["sclk_mhz"] / 2400.0, 1)
