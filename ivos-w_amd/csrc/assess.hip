@@ -382,9 +382,12 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     // ... and res2's last block then writes its output at the even pixels only (compact [nb,32,32,256]): with conv1 forwarded, the
     // only reader left is res3's stride-2 downsample.  Off when an intermediate is tapped (the res2 tap wants the whole tensor).
     const bool ys2 = fwd2 && tap_stage == 0 && tune_get("FUSE_DS", 1) && tune_get("YS2", 1);
-    // ... or the whole of res2 in ONE launch (res2_stage.hip, tunable RES2_STAGE): a workgroup carries its 8 x 16 tile through the
-    // three blocks, y0 / y1 never reach HBM.  Same summation orders as the per-block kernels: bit-identical stage output.
-    const bool stage2 = fwd2 && tune_get("RES2_STAGE", 0);
+    // ... or the whole of res2 in ONE launch (res2_stage.hip, tunable RES2_STAGE, default on): a workgroup carries its 8 x 16 tile
+    // through the three blocks, y0 / y1 never reach HBM.  Same summation orders as the per-block kernels: bit-identical stage output, so
+    // the choice moves no score.  In time the two are level (frames/s at B = 32 / 64 / 100 / 160 / 256: +0.8 / -1.2 / +1.9 / -0.6 /
+    // -0.8 %, alternating runs on one box; 946 against 983 us on one stream); the stage kernel moves 2.55 GB less HBM traffic per
+    // 256-frame pass (9.23 against 11.77 GB) in four launches fewer, which is why it is the default.
+    const bool stage2 = fwd2 && tune_get("RES2_STAGE", 1);
     auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {
         const char* x = x_in;
         int hw = hw_in[s];

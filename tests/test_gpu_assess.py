@@ -438,7 +438,7 @@ def test_res2_stage_kernel_is_bit_identical_to_the_per_block_kernels(dev, net16)
                 lib.ivosw_tune_set(b"RES2_STAGE", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3")] + [net(ttf, ttp).clone()]
         finally:
-            lib.ivosw_tune_set(b"RES2_STAGE", 0)      # the default (assess.hip)
+            lib.ivosw_tune_set(b"RES2_STAGE", 1)      # the default (assess.hip)
         for a, b, nm in zip(got[1], got[0], ("res2", "res3", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
