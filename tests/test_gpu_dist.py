@@ -118,12 +118,12 @@ def test_world2_product_path_matches_single_process_full_batch(mode):
     assert np.array_equal(res[0][-1][2], res[0][-1][1]) == bool(torch.equal(agent.target_net.flat, agent.policy_net.flat))
 
 
-@pytest.mark.parametrize("variant", ["default", "graph_no_p2p", "strong"])
+@pytest.mark.parametrize("variant", ["default", "p2p_leg", "graph_no_p2p", "strong"])
 def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     """bench.py's N > 1 branch exactly as the driver launches it (torch.distributed.run, one process per rank, barrier + max over
     ranks, rank 0 prints the line) — on this one-GPU box with both ranks on cuda:0 and the gloo rendezvous (two ranks cannot
-    share a device under RCCL).  default: plain launches + the one-shot peer-to-peer all-reduce (IPC-mapped arenas of the two
-    processes); graph_no_p2p: captured gradient graph + the collective of the backend (IVOSW_P2P=0: gloo staged through host memory).  Frames are sharded (weak scaling), the DQN leg all-reduces
+    share a device under RCCL).  default: plain launches + the backend's all-reduce only; p2p_leg (IVOSW_BENCH_P2P=1): the one-shot
+    peer-to-peer all-reduce (IPC-mapped arenas of the two processes) is timed as a second leg; graph_no_p2p: captured gradient graph + the collective of the backend (IVOSW_P2P=0: gloo staged through host memory).  Frames are sharded (weak scaling), the DQN leg all-reduces
     its gradient arena every step."""
     import json
     import subprocess
@@ -135,6 +135,8 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     s_.close()
     env = dict(os.environ, IVOSW_BENCH_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     extra = []
+    if variant == "p2p_leg":
+        env["IVOSW_BENCH_P2P"] = "1"
     if variant == "graph_no_p2p":
         env["IVOSW_P2P"] = "0"
         extra = ["--dqn-dp", "graph"]
@@ -156,9 +158,10 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     assert d["dqn"]["value"] > 0 and "all-reduce" in d["dqn"]["collective"]
     if variant == "strong":
         return
-    if variant == "default":
-        legs = d["dqn"]["collectives"]                       # both collective paths are timed; the faster validated one is dqn.value
-        assert set(legs) == {"backend", "p2p"} and all(v.get("us_per_step", 0) > 0 for v in legs.values()), legs
+    if variant in ("default", "p2p_leg"):
+        legs = d["dqn"]["collectives"]                       # the timed collective paths; the faster validated one is dqn.value
+        assert set(legs) == ({"backend", "p2p"} if variant == "p2p_leg" else {"backend"}), legs
+        assert all(v.get("us_per_step", 0) > 0 for v in legs.values()), legs
         assert d["dqn"]["graph"] is False
     else:
         assert "gloo" in d["dqn"]["collective"] and d["dqn"]["graph"] is True
