@@ -351,6 +351,20 @@ def test_b256_headline_configuration(dev, net16, net32):
     np.testing.assert_allclose(full.cpu().numpy()[pick], ref.reshape(-1), rtol=BF16_SCORE_RTOL)
 
 
+def test_b256_forward_is_deterministic_over_many_passes(dev, net16):
+    """Soak: 300 back-to-back bf16 forwards of the 256-frame batch (two streams, the one-launch res2 stage kernel, the chained res4
+    kernel with its staggered start) must return the first pass's scores bit for bit — a missing barrier or an LDS region reused a
+    phase too early shows up as a rare flipped bit long before it shows up in a tolerance."""
+    tf, tp = synth.assess_inputs(16, seed=77, structured=True)
+    ttf, ttp = _variants(torch.from_numpy(tf).to(dev), torch.from_numpy(tp).to(dev), 256)
+    first = net16(ttf, ttp).reshape(-1).clone()
+    acc = torch.zeros((), dtype=torch.int64, device=dev)
+    for _ in range(300):
+        s = net16(ttf, ttp).reshape(-1)
+        acc += (s.view(torch.int32) != first.view(torch.int32)).sum()
+    assert int(acc.item()) == 0
+
+
 def _ranks(a):
     r = np.empty(len(a))
     r[np.argsort(a, kind="stable")] = np.arange(len(a))
