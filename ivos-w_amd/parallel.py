@@ -70,7 +70,8 @@ class P2PAllReduce:
     unless every rank passes, all of them get ``None`` back (and use RCCL).
 
     OPT-IN (``IVOSW_P2P=1``): the cross-GPU write path has only ever run between two processes on one MI355X, so the product
-    default is the backend's all-reduce (RCCL over xGMI) until an 8-GPU node has validated it; ``bench.py --gpus N`` times both.
+    default is the backend's all-reduce (RCCL over xGMI) until an 8-GPU node has validated it; ``IVOSW_BENCH_P2P=1 bench.py --gpus N``
+    times both.
     ``IVOSW_P2P_SELFTEST_FAIL=<rank>`` makes that rank report a failed self-test (fault injection: every rank must then end up
     on the backend path).  A peer that does not arrive within ``timeout_ms`` does NOT hang the GPU and is NOT silent either: the
     reduce kernels leave their outputs untouched and set the arena's error word, which ``check()`` reads (every call in
@@ -297,10 +298,12 @@ class RankBatchSampler:
 
     def __init__(self, n, batch_size, rank_, world_, seed):
         self.n, self.batch_size, self.rank, self.world, self.seed = int(n), int(batch_size), int(rank_), int(world_), int(seed)
+        self.epoch = 0
 
     def __iter__(self):
         g = torch.Generator()
-        g.manual_seed(self.seed)
+        g.manual_seed(self.seed + 7919 * self.epoch)         # a fresh permutation per pass over the loader, the same on every rank
+        self.epoch += 1
         perm = torch.randperm(self.n, generator=g).tolist()
         batches = [perm[i:i + self.batch_size] for i in range(0, self.n, self.batch_size)]
         for k in range(len(self)):

@@ -102,3 +102,8 @@ def test_rank_batch_sampler_deals_the_shuffled_minibatches_out():
     from torch.utils.data import DataLoader
     dl = DataLoader(list(range(n)), batch_sampler=RankBatchSampler(n, B, 0, world, 77))
     assert [b.tolist() for b in dl] == per_rank[0]
+    second = [b.tolist() for b in dl]                        # a second pass over the same loader: a fresh permutation, again shared
+    assert second != per_rank[0] and sorted(sum(second, [])) != [] and len(second) == len(per_rank[0])
+    other = RankBatchSampler(n, B, 1, world, 77)
+    list(other)
+    assert not set(sum(second, [])) & set(sum(list(other), []))
