@@ -155,17 +155,14 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
             if (tile_px(pq + 2 * i, cyl, cxl)) {
                 const int p = cyl * CT + cxl;
                 const int cy = 2 * py0 - 1 + cyl, cx = 2 * px0 - 1 + cxl;
-                const bool in = cy >= 0 && cy < 128 && cx >= 0 && cx < 128;
+                const unsigned in = (cy >= 0 && cy < 128 && cx >= 0 && cx < 128) ? 0xffffffffu : 0u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    // ReLU as ONE instruction: fmaxf(x, 0) on a raw MFMA result costs a second v_max that only quiets NaNs
-                    // (hipcc lowers fmed3 the same way), so the v_max is spelled out
-                    auto relu1 = [](float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; };
-                    const float v0 = relu1(acc[i][4 * g]), v1 = relu1(acc[i][4 * g + 1]);
-                    const float v2 = relu1(acc[i][4 * g + 2]), v3 = relu1(acc[i][4 * g + 3]);
+                    // ReLU as ONE packed-int16 max AFTER the bf16 conversion (relu2_bf16: the same bits as max-then-round, a quarter
+                    // of the v_max), the map border as an AND
                     uint2 pk;
-                    pk.x = in ? pack2_bf16(v0, v1) : 0u;
-                    pk.y = in ? pack2_bf16(v2, v3) : 0u;
+                    pk.x = relu2_bf16(acc[i][4 * g], acc[i][4 * g + 1]) & in;
+                    pk.y = relu2_bf16(acc[i][4 * g + 2], acc[i][4 * g + 3]) & in;
                     *reinterpret_cast<uint2*>(lds + CO_OFF + p * 128 + (((ct * 4 + g) ^ (p & 7)) << 4) + 8 * kh) = pk;
                 }
             }
