@@ -388,6 +388,12 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     // -0.8 %, alternating runs on one box; 946 against 983 us on one stream); the stage kernel moves 2.55 GB less HBM traffic per
     // 256-frame pass (9.23 against 11.77 GB) in four launches fewer, which is why it is the default.
     const bool stage2 = fwd2 && tune_get("RES2_STAGE", 1);
+    // Snake order (tunable SNAKE, default on): consecutive launches of the tower walk their pixel tiles in OPPOSITE directions, so a
+    // launch starts with the tiles its producer wrote last - still in the memory-side cache (256 MB for ~128 MB tensors per stream) -
+    // instead of the ones written first and long evicted.  Tiles are independent: the order cannot change a result.
+    const bool snake = dtype == IVOSW_BF16 && tune_get("SNAKE", 1) != 0;
+    int dir = 1;                                     // the stem walks forward; the first launch behind it walks backward
+    auto next_dir = [&]() { const int d = snake ? dir : 0; dir ^= 1; return d; };
     auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {
         const char* x = x_in;
         int hw = hw_in[s];
@@ -395,6 +401,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
             Res2StageArgs q = res2_stage_args(P, base);
             q.x = x; q.y = out; q.t1out = bf.m1 + (size_t)foff * 64 * 64 * 128 * es;
             q.B = nb; q.y_s2 = ys2 ? 1 : 0;
+            q.rev = next_dir();
             if (res2_stage_ok(q)) {
                 launch_res2_stage(q, st);
                 return;
@@ -410,6 +417,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 q.zeros = base + P.zero_off; q.x = in; q.w = base + c.w_off; q.bias = reinterpret_cast<const float*>(base + c.b_off); q.res = res; q.y = o;
                 q.B = nb; q.H = hin; q.W = hin; q.Cin = c.Cin; q.Ho = hout; q.Wo = hout; q.Cout = c.Cout;
                 q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
+                q.rev = next_dir();
                 if (dtype == IVOSW_BF16 && c.fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + c.fw_off, st);
                 else launch_conv(q, dtype, false, st);
             };
@@ -423,6 +431,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     q.ds = 1; q.fc = base + bp.cat_fw_off; q.bc = reinterpret_cast<const float*>(base + bp.cat_b_off);
                 }
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
+                q.rev = next_dir();
                 if (s == 0 && fwd2) {
                     // t1 ping-pong: b0 -> m2 -> b1 -> ds -> b2 -> m1 (res3's t1 for the frames of the enclosing res3 chunk)
                     const BlockPlan& nx = P.blocks[first_blk[0] + b + 1];          // the next block (res3's first after b == 2)
@@ -490,6 +499,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 q.res = nullptr; q.y = y; q.B = nb; q.H = ho; q.W = ho; q.Cin = c3.Cin; q.Ho = ho; q.Wo = ho; q.Cout = c3.Cout;
                 q.KH = 1; q.KW = 1; q.stride = 1; q.pad = 0; q.relu = 1;
                 q.x2 = x; q.Cin2 = cd.Cin; q.H2 = hw; q.W2 = hw; q.stride2 = cd.stride;
+                q.rev = next_dir();
                 if (s == 1 && ys2) { q.H2 = hw / 2; q.W2 = hw / 2; q.stride2 = 1; }      // res2's output arrives already subsampled
                 if (dtype == IVOSW_BF16 && bp.cat_fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + bp.cat_fw_off, st);
                 else launch_conv(q, dtype, false, st);

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhalf = lane >> 5;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int L = p.rev ? (int)gridDim.x - 1 - xcd_remap(blockIdx.x, gridDim.x) : xcd_remap(blockIdx.x, gridDim.x);
     const int b = L / TPF, tl = L - b * TPF;
     const int y0 = (tl / TPX) * BT, x0 = (tl % TPX) * BT;
     const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * HW * HW * CIN;
@@ -1835,7 +1835,7 @@ __global__ __launch_bounds__(512) void conv1x1_wide_kernel(ConvArgs p, const voi
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int nbn = p.Cout / 256;
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = L % nbn, tile_m = L / nbn;
+    const int tile_n = L % nbn, tile_m = p.rev ? (int)gridDim.x / nbn - 1 - L / nbn : L / nbn;
     const int m0 = tile_m * 256;
     const int M = p.B * p.Ho * p.Wo;
     const bf16_t* X = static_cast<const bf16_t*>(p.x);

@@ -19,6 +19,7 @@ struct ConvArgs {
     int nmajor;         // tile order of the wave-specialised kernel: 0 m-major, 1 n-major
     int nt;             // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (generic epilogue), bit 2: also in the patch / fused kernels (tunable NT, default 3)
     int debug;          // ablation bits (IVOSW_DEBUG_CONV, tuning only): 1 skip epilogue stores, 2 skip MFMA, 4 skip DMA after the first tile
+    int rev;            // 1: pixel tiles are taken in DESCENDING order (see BneckWideArgs::rev; tunable SNAKE)
 };
 
 void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st);
@@ -67,6 +68,7 @@ struct BneckWideArgs {
     const void* fd; const float* bd;   // that conv1 [nd][4*Cmid] in fragment order, and its bias
     int nd;                            // 64 (next block of res2) or 128 (first block of res3)
     int y_s2;                          // 1: y is written at the even pixels only, compactly [B,H/2,W/2,4*Cmid] (its only consumer is a stride-2 1x1)
+    int rev;                           // 1: tiles are taken in DESCENDING order (the launch starts with what the previous launch wrote last)
 };
 // a run of consecutive identity blocks of one stage (res4: one frame per workgroup) in ONE launch
 struct BneckStageArgs {
@@ -88,6 +90,7 @@ struct Res2StageArgs {
     int B, y_s2;
     unsigned long long* ts;            // optional [grid][16] s_memtime stamps at the phase boundaries (ivosw_res2_stage_probe)
     int debug;                         // IVOSW_ABLATION builds only (tunable R2DBG): 1 no weight loads, 2 pixel fragments read once per phase, 4 no MFMAs
+    int rev;                           // 1: tiles in descending order
 };
 bool res2_stage_ok(const Res2StageArgs& a);
 void launch_res2_stage(const Res2StageArgs& a, hipStream_t st);

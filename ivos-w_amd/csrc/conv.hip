@@ -459,7 +459,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
     // tile order: m-major (the n-tiles of one m-tile adjacent on one XCD: the A tile is fetched from HBM once) or
     // n-major (an XCD keeps ONE weight slice in its L2 and walks the m-tiles: for slices too big to share an L2)
     const int nbm = gridDim.x / nbn;
-    const int tile_n = p.nmajor ? L / nbm : L % nbn, tile_m = p.nmajor ? L % nbm : L / nbn;
+    const int tile_n = p.nmajor ? L / nbm : L % nbn, tile_m0 = p.nmajor ? L % nbm : L / nbn;
+    const int tile_m = p.rev ? nbm - 1 - tile_m0 : tile_m0;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int M = p.B * p.Ho * p.Wo;
     const int K = p.KH * p.KW * p.Cin + (p.x2 ? p.Cin2 : 0);
@@ -648,7 +649,8 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
     // n-major (p.nmajor): the workgroups of one XCD share ONE 128-channel weight slice (its L2 keeps it: the weight
     // tiles are ~85 % of the fill bytes here); m-major: the n-tiles of one pixel tile share its patch instead
     const int nbm = gridDim.x / nbn;
-    const int tile_n = p.nmajor ? L / nbm : L % nbn, tile_m = p.nmajor ? L % nbm : L / nbn;
+    const int tile_n = p.nmajor ? L / nbm : L % nbn, tile_m0 = p.nmajor ? L % nbm : L / nbn;
+    const int tile_m = p.rev ? nbm - 1 - tile_m0 : tile_m0;
     const int n0 = tile_n * BN;
     const int tpf = (p.H / TH) * (p.W / TW);                 // tiles per frame (1 when a tile spans F whole frames)
     const int b0 = (F > 1) ? tile_m * F : tile_m / tpf;

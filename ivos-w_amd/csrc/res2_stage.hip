@@ -375,8 +375,9 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
     int lrow = lane & 31, lhalf = lane >> 5;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
-    const int ntiles = p.B * 32, wslot = xcd_remap(blockIdx.x, gridDim.x);     // consecutive logical tiles on one XCD: neighbours share halos through that L2
-    if (wslot >= ntiles) return;
+    const int ntiles = p.B * 32, wslot0 = xcd_remap(blockIdx.x, gridDim.x);    // consecutive logical tiles on one XCD: neighbours share halos through that L2
+    if (wslot0 >= ntiles) return;
+    const int wslot = p.rev ? ntiles - 1 - wslot0 : wslot0;
     int b, y0, x0;
     const bf16_t* X;
     auto set_tile = [&](int t) {

@@ -434,6 +434,26 @@ def test_conv1_forwarding_through_res2_is_bit_identical(dev, net16):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
 
+def test_snake_order_of_the_tower_launches_is_invisible(dev, net16):
+    """bf16 mode: consecutive launches of the tower walk their pixel tiles in opposite directions (tunable SNAKE=1, default), so a launch
+    starts with what its producer wrote last.  Tiles are independent: every tap and the scores equal the forward-only order bit for bit,
+    for a full batch with edge masks, an odd batch and a chunked one."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge, chunk in ((8, True, 0), (3, False, 0), (6, False, 2)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
+        got = {}
+        try:
+            for mode in (1, 0):
+                lib.ivosw_tune_set(b"SNAKE", mode)
+                got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3", "res4", "res5")] + [net(ttf, ttp).clone()]
+        finally:
+            lib.ivosw_tune_set(b"SNAKE", 1)
+        for a, b, nm in zip(got[1], got[0], ("res2", "res3", "res4", "res5", "scores")):
+            assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
+
+
 def test_res2_stage_kernel_is_bit_identical_to_the_per_block_kernels(dev, net16):
     """bf16 mode: the whole of res2 (three bottlenecks + res3's forwarded conv1) in ONE launch (res2_stage.hip, tunable
     RES2_STAGE=1): a workgroup carries its 8 x 16 tile through the three blocks on shrinking halos, y0 / y1 never reach HBM and the
