@@ -391,7 +391,8 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     // Snake order (tunable SNAKE, default on): consecutive launches of the tower walk their pixel tiles in OPPOSITE directions, so a
     // launch starts with the tiles its producer wrote last - still in the memory-side cache (256 MB for ~128 MB tensors per stream) -
     // instead of the ones written first and long evicted.  Tiles are independent: the order cannot change a result.
-    const bool snake = dtype == IVOSW_BF16 && tune_get("SNAKE", 1) != 0;
+    // From SNAKE_MIN (96) frames per stream: below that the tensors fit the cache either way (B = 32 / 100 / 160: +-0 / -0.6 / +0.4 %).
+    const bool snake = dtype == IVOSW_BF16 && tune_get("SNAKE", 1) != 0 && B >= tune_get("SNAKE_MIN", 96);
     int dir = 1;                                     // the stem walks forward; the first launch behind it walks backward
     auto next_dir = [&]() { const int d = snake ? dir : 0; dir ^= 1; return d; };
     auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {

@@ -445,11 +445,13 @@ def test_snake_order_of_the_tower_launches_is_invisible(dev, net16):
         net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
         got = {}
         try:
+            lib.ivosw_tune_set(b"SNAKE_MIN", 1)          # (the default applies the order from 96 frames per stream)
             for mode in (1, 0):
                 lib.ivosw_tune_set(b"SNAKE", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3", "res4", "res5")] + [net(ttf, ttp).clone()]
         finally:
             lib.ivosw_tune_set(b"SNAKE", 1)
+            lib.ivosw_tune_set(b"SNAKE_MIN", 96)
         for a, b, nm in zip(got[1], got[0], ("res2", "res3", "res4", "res5", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
