@@ -393,7 +393,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     // instead of the ones written first and long evicted.  Tiles are independent: the order cannot change a result.
     // From SNAKE_MIN (96) frames per stream: below that the tensors fit the cache either way (B = 32 / 100 / 160: +-0 / -0.6 / +0.4 %).
     const bool snake = dtype == IVOSW_BF16 && tune_get("SNAKE", 1) != 0 && B >= tune_get("SNAKE_MIN", 96);
-    int dir = 1;                                     // the stem walks forward; the first launch behind it walks backward
+    int dir = 1;                                     // the stem walks backward (its producer, the ROI crop, walks forward), the launch behind it forward ...
     auto next_dir = [&]() { const int d = snake ? dir : 0; dir ^= 1; return d; };
     auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {
         const char* x = x_in;
@@ -533,7 +533,8 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     // K4: stem 7x7/2 (RGB|P) + BN + ReLU, then 3x3/2 max pool (bf16: one fused kernel unless the stem tap is wanted)
                     span_open(st, slot);
                     if (dtype == IVOSW_BF16 && tap_stage != 2 && tune_get("FUSE_STEM", 1)) {
-                        launch_stem_pool(bf.roi, base + P.stem_w_off, reinterpret_cast<const float*>(base + P.stem_b_off), nb, bf.pa, st);
+                        dir = 1;                 // every res2 chunk starts the alternation anew at its stem
+                        launch_stem_pool(bf.roi, base + P.stem_w_off, reinterpret_cast<const float*>(base + P.stem_b_off), nb, bf.pa, st, next_dir());
                     } else {
                         ConvArgs a{};
                         a.zeros = base + P.zero_off; a.x = bf.roi; a.w = base + P.stem_w_off; a.bias = reinterpret_cast<const float*>(base + P.stem_b_off);

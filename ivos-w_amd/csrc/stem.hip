@@ -38,7 +38,7 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 // Persistent: each workgroup loads the filter bank once and walks over tiles (tile id = first + k * stride); the next
 // tile's input patch is fetched into registers while the current tile is in the matrix cores.
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restrict__ roi, const bf16_t* __restrict__ wpk,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int ntiles) {
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int ntiles, int rev) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[STEM_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
         pc_[j] = i - pr_[j] * PW;
     }
     uint2 pre[NPRE];
-    auto patch_fetch = [&](int t) {              // tile t -> registers (zero outside the 256 x 256 ROI tile and in col 39)
+    auto patch_fetch = [&](int t_) {             // tile t -> registers (zero outside the 256 x 256 ROI tile and in col 39)
+        const int t = rev ? ntiles - 1 - t_ : t_;    // (rev: the tiles in descending order, see BneckWideArgs::rev)
         const int b = t >> 6, tl = t & 63;
         const bf16_t* img = roi + (size_t)b * 256 * 256 * 4;
         const int iy0 = 4 * (tl >> 3) * PT - 5, ix0 = 4 * (tl & 7) * PT - 5;
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
     for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(bias + ct * 32 + 8 * g + 4 * kh);
 
     for (; t < ntiles; t += gridDim.x) {
-        const int b = t >> 6, tl = t & 63;
+        const int tt = rev ? ntiles - 1 - t : t;
+        const int b = tt >> 6, tl = tt & 63;
         const int py0 = (tl >> 3) * PT, px0 = (tl & 7) * PT;
         patch_store();                            // (the previous tile's pooling is behind the barrier at the loop end)
         __syncthreads();
@@ -190,14 +192,14 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const bf16_t* __restr
     }
 }
 
-void launch_stem_pool(const void* roi, const void* w, const float* bias, int B, void* out, hipStream_t st) {
+void launch_stem_pool(const void* roi, const void* w, const float* bias, int B, void* out, hipStream_t st, int rev) {
     ConvArgs d{};
     d.B = B; d.H = 256; d.W = 256; d.Cin = 4; d.Ho = 128; d.Wo = 128; d.Cout = 64; d.KH = 7; d.KW = 7; d.stride = 2;
     void* tok = prof_begin(d, 2, st);
     const int ntiles = B * 64;
     const int grid = ntiles < 512 ? ntiles : 512;             // 2 workgroups per CU (78 KB of LDS each), persistent over the tiles
     hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(roi), static_cast<const bf16_t*>(w),
-                       bias, static_cast<bf16_t*>(out), ntiles);
+                       bias, static_cast<bf16_t*>(out), ntiles, rev);
     prof_end(tok, st);
 }
 
