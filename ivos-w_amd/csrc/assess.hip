@@ -451,7 +451,9 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     for (int bb = b; bb < nblk[s]; ++bb) {
                         const BlockPlan& bq = P.blocks[first_blk[s] + bb];
                         const ConvPlan &d1 = P.convs[bq.c1], &d2 = P.convs[bq.c2], &d3 = P.convs[bq.c3];
-                        char* yi = (bb == nblk[s] - 1) ? out : ((xi == bf.pa) ? bf.pb : bf.pa);
+                        // in place (tunable INPLACE4): a frame belongs to ONE workgroup, phase A has consumed x before phase C writes, and an
+                        // element of y goes where the residual it was formed from came from - half the footprint of the chain in the caches
+                        char* yi = (bb == nblk[s] - 1) ? out : ((tune_get("INPLACE4", 1) && bb > b) ? const_cast<char*>(xi) : ((xi == bf.pa) ? bf.pb : bf.pa));
                         BneckWideArgs& r = sa.blk[sa.n++];
                         r = q;
                         r.x = xi; r.y = yi;

@@ -217,22 +217,28 @@ def test_wide_1x1_conv_matches_tiled_kernel(dev, net16):
 def test_chained_res4_blocks_are_bit_identical_to_separate_launches(dev, net16):
     """bf16 mode: res4's five identity blocks chained inside one launch (tunable STAGE_RUN=1, default; the workgroup that
     wrote a frame is its only reader, workgroup-scope release / acquire between blocks) against one launch per block:
-    the same kernel body on the same data -> bit-identical stage output and scores, for a full and a ragged batch."""
+    the same kernel body on the same data -> bit-identical stage output and scores, for a full and a ragged batch.  The chain runs IN
+    PLACE from its second block on (tunable INPLACE4=1, default: a frame belongs to one workgroup, phase A has consumed x before phase C
+    writes, and an element of y goes where the residual it was formed from came from), which halves its footprint in the caches."""
     from ivos_w_amd import _lib as L
     lib = L.lib()
     for B, edge in ((8, True), (3, False)):
         _, _, ttf, ttp = inputs(dev, B, edge)
+        got = {}
         try:
-            lib.ivosw_tune_set(b"STAGE_RUN", 1)
-            _, a = net16.forward_tap(ttf, ttp, "res4")
-            sa = net16(ttf, ttp).cpu().numpy()
-            lib.ivosw_tune_set(b"STAGE_RUN", 0)
-            _, b = net16.forward_tap(ttf, ttp, "res4")
-            sb = net16(ttf, ttp).cpu().numpy()
+            lib.ivosw_tune_set(b"HALF16_MAX", 0)         # (launches this small would take the half-frame kernel, block by block)
+            # chained + in place (default: blocks 2 .. 4 of the chain write y over their x) | chained, ping-pong buffers | one launch per block
+            for key, run, inplace in (("inplace", 1, 1), ("chained", 1, 0), ("separate", 0, 0)):
+                lib.ivosw_tune_set(b"STAGE_RUN", run)
+                lib.ivosw_tune_set(b"INPLACE4", inplace)
+                got[key] = (net16.forward_tap(ttf, ttp, "res4")[1].clone(), net16.forward_tap(ttf, ttp, "res5")[1].clone(), net16(ttf, ttp).cpu().numpy())
         finally:
             lib.ivosw_tune_set(b"STAGE_RUN", 1)
-        assert torch.equal(a, b)
-        np.testing.assert_array_equal(sa, sb)
+            lib.ivosw_tune_set(b"INPLACE4", 1)
+            lib.ivosw_tune_set(b"HALF16_MAX", 96)
+        for key in ("chained", "separate"):
+            assert torch.equal(got["inplace"][0], got[key][0]) and torch.equal(got["inplace"][1], got[key][1]), key
+            np.testing.assert_array_equal(got["inplace"][2], got[key][2])
 
 
 def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
