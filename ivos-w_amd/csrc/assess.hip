@@ -444,6 +444,35 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     q.nd = n1c.Cout;
                     q.y_s2 = (b == 2 && ys2) ? 1 : 0;
                 }
+                if (s == 1 && b == 1 && bp.ds < 0 && snake && bneck_wide_fusable(q) && tune_get("DF3", 2) > 1 && nb >= tune_get("DF3_MIN", 128)) {
+                    // res3's three identity blocks DEPTH FIRST over DF3 (2) groups of the launch's frames: b1 b2 b3 for the first half, then
+                    // for the second.  Every block's input was written by the launch right before it and its x + y (64 + 64 MB per stream
+                    // instead of 128 + 128) fit the memory-side cache together with the other stream's.  Costs the tail balancing of a
+                    // 512-workgroup launch (256 workgroups are a single round): + 1.4 % frames/s at 128 frames per stream, - 0.5 % with four
+                    // groups; a frame's result does not depend on the launch it travels in.
+                    const size_t fe = (size_t)hw * hw * c1.Cin * es;
+                    const int G = tune_get("DF3", 2);
+                    char* y1 = (x == bf.pa) ? bf.pb : bf.pa;
+                    char* y2 = (y1 == bf.pa) ? bf.pb : bf.pa;
+                    char* bufs[4] = {const_cast<char*>(x), y1, y2, out};
+                    for (int g = 0; g < G; ++g) {
+                        const int lo = (int)((long)nb * g / G), hi = (int)((long)nb * (g + 1) / G);
+                        for (int bb = 1; bb <= 3; ++bb) {
+                            const BlockPlan& bq = P.blocks[first_blk[1] + bb];
+                            const ConvPlan &d1 = P.convs[bq.c1], &d2 = P.convs[bq.c2], &d3 = P.convs[bq.c3];
+                            BneckWideArgs r = q;
+                            r.fa = base + bq.f1_off; r.ba = reinterpret_cast<const float*>(base + d1.b_off);
+                            r.fb = base + bq.f2_off; r.bb = reinterpret_cast<const float*>(base + d2.b_off);
+                            r.fc = base + bq.f3_off; r.bc = reinterpret_cast<const float*>(base + d3.b_off);
+                            r.x = bufs[bb - 1] + (size_t)lo * fe; r.y = bufs[bb] + (size_t)lo * fe;
+                            r.B = hi - lo;
+                            r.rev = next_dir();
+                            launch_bneck_wide(r, st);
+                        }
+                    }
+                    x = out;
+                    break;
+                }
                 if (bp.ds < 0 && bneck_wide_fusable(q) && bneck_stage_fusable(q) && b + 1 < nblk[s]) {
                     // the rest of the stage is identity blocks of this shape: chain them inside one launch
                     BneckStageArgs sa{};
