@@ -448,8 +448,8 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     // res3's three identity blocks DEPTH FIRST over DF3 (2) groups of the launch's frames: b1 b2 b3 for the first half, then
                     // for the second.  Every block's input was written by the launch right before it and its x + y (64 + 64 MB per stream
                     // instead of 128 + 128) fit the memory-side cache together with the other stream's.  Costs the tail balancing of a
-                    // 512-workgroup launch (256 workgroups are a single round): + 1.4 % frames/s at 128 frames per stream, - 0.5 % with four
-                    // groups; a frame's result does not depend on the launch it travels in.
+                    // 512-workgroup launch (256 workgroups are a single round): + 0.8 % frames/s on average over five boxes at 128 frames per
+                    // stream (- 0.2 .. + 2.5 %), - 0.5 % with four groups; a frame's result does not depend on the launch it travels in.
                     const size_t fe = (size_t)hw * hw * c1.Cin * es;
                     const int G = tune_get("DF3", 2);
                     char* y1 = (x == bf.pa) ? bf.pb : bf.pa;
