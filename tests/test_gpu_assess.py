@@ -462,6 +462,28 @@ def test_snake_order_of_the_tower_launches_is_invisible(dev, net16):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
 
+def test_depth_first_res3_and_uneven_halves_are_invisible(dev, net16):
+    """bf16, B = 264 (two streams: 136 + 128 frames): res3's identity blocks run depth first over two groups of a launch of >= 128
+    frames (tunables DF3 / DF3_MIN: 68 + 68 and 64 + 64 frames here), in snake order, res4's chain in place.  A frame's score does not
+    depend on the launch it travels in: the batch equals its 8-frame pieces bit for bit, and the schedule switched off (DF3=1,
+    SNAKE=0, INPLACE4=0) gives the same bits."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    tf, tp = synth.assess_inputs(16, seed=99, structured=True)
+    ttf, ttp = _variants(torch.from_numpy(tf).to(dev), torch.from_numpy(tp).to(dev), 264)
+    full = net16(ttf, ttp).reshape(-1).clone()
+    part = torch.cat([net16(ttf[lo:lo + 8], ttp[lo:lo + 8]).reshape(-1) for lo in range(0, 264, 8)])
+    assert torch.equal(part, full)
+    try:
+        for k, v in ((b"DF3", 1), (b"SNAKE", 0), (b"INPLACE4", 0)):
+            lib.ivosw_tune_set(k, v)
+        plain = net16(ttf, ttp).reshape(-1).clone()
+    finally:
+        for k, v in ((b"DF3", 2), (b"SNAKE", 1), (b"INPLACE4", 1)):
+            lib.ivosw_tune_set(k, v)
+    assert torch.equal(plain, full)
+
+
 def test_res2_stage_kernel_is_bit_identical_to_the_per_block_kernels(dev, net16):
     """bf16 mode: the whole of res2 (three bottlenecks + res3's forwarded conv1) in ONE launch (res2_stage.hip, tunable
     RES2_STAGE=1): a workgroup carries its 8 x 16 tile through the three blocks on shrinking halos, y0 / y1 never reach HBM and the
