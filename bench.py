@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py — throughput of the IVOS-W hot path on MI355X (one process per GPU).
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, or plainly — it then
+                                                              re-executes itself under torch.distributed.run, one rank per GPU)
 
 Default workload = BASELINE.json configs[1]: the assessment CNN (AssessNet.forward) on a batch of 256
 synthetic 480p (frame, mask) pairs per GPU, bf16 operands / fp32 accumulate, inputs resident in HBM when
@@ -68,7 +69,7 @@ def agent_cfg():
 def dist_setup(n):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if n > 1 and world != n:
-        raise SystemExit(f"--gpus {n} needs torch.distributed.run with nproc-per-node {n} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {n} under a launcher with WORLD_SIZE={world}: the two must agree")
     # --backend gloo + IVOSW_BENCH_SAME_DEVICE=1: every rank on cuda:0 with host-staged collectives — the only way to run the
     # multi-rank code path on a one-GPU box (tests/test_gpu_dist.py); the driver's 2/4/8-GPU runs use nccl = RCCL over xGMI
     if os.environ.get("IVOSW_BENCH_SAME_DEVICE") == "1":
@@ -87,6 +88,13 @@ def dist_setup(n):
 
 
 BACKEND = ["nccl"]
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
 
 
 def reduce_scalar(dist, value, op, dev):
@@ -828,6 +836,12 @@ def main():
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: become the launcher — one rank per GPU under torch.distributed.run, exactly the
+        # command the driver uses (rendezvous on 127.0.0.1: the container hostname may not resolve); rank 0 prints the line
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:])
     BACKEND[0] = args.backend
     rank, world, dev, dist = dist_setup(args.gpus)
     args.total_batch = args.batch * world

@@ -118,13 +118,14 @@ def test_world2_product_path_matches_single_process_full_batch(mode):
     assert np.array_equal(res[0][-1][2], res[0][-1][1]) == bool(torch.equal(agent.target_net.flat, agent.policy_net.flat))
 
 
-@pytest.mark.parametrize("variant", ["default", "p2p_leg", "graph_no_p2p", "strong"])
+@pytest.mark.parametrize("variant", ["default", "plain", "p2p_leg", "graph_no_p2p", "strong"])
 def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     """bench.py's N > 1 branch exactly as the driver launches it (torch.distributed.run, one process per rank, barrier + max over
     ranks, rank 0 prints the line) — on this one-GPU box with both ranks on cuda:0 and the gloo rendezvous (two ranks cannot
     share a device under RCCL).  default: plain launches + the backend's all-reduce only; p2p_leg (IVOSW_BENCH_P2P=1): the one-shot
     peer-to-peer all-reduce (IPC-mapped arenas of the two processes) is timed as a second leg; graph_no_p2p: captured gradient graph + the collective of the backend (IVOSW_P2P=0: gloo staged through host memory).  Frames are sharded (weak scaling), the DQN leg all-reduces
-    its gradient arena every step."""
+    its gradient arena every step.  plain: `python bench.py --gpus 2 ...` with NO launcher in front — bench.py re-executes itself under
+    torch.distributed.run (the driver's scaling run may be started that way) and still prints exactly one line."""
     import json
     import subprocess
     import sys
@@ -146,6 +147,10 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--min-warm-s", "0",
            "--batch", "16", "--dqn-steps", "30", "--backend", "gloo", "--no-fp32"] + extra
+    if variant == "plain":
+        cmd = [sys.executable] + cmd[cmd.index(os.path.join(root, "bench.py")):]
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -158,7 +163,7 @@ def test_bench_multi_rank_branch_under_torchrun(tmp_path, variant):
     assert d["dqn"]["value"] > 0 and "all-reduce" in d["dqn"]["collective"]
     if variant == "strong":
         return
-    if variant in ("default", "p2p_leg"):
+    if variant in ("default", "plain", "p2p_leg"):
         legs = d["dqn"]["collectives"]                       # the timed collective paths; the faster validated one is dqn.value
         assert set(legs) == ({"backend", "p2p"} if variant == "p2p_leg" else {"backend"}), legs
         assert all(v.get("us_per_step", 0) > 0 for v in legs.values()), legs
