@@ -350,11 +350,11 @@ def bench_assess(args, rank, world, dev, dist):
     else:
         sus = {"value": round(fps, 1), "steps": args.steps, "seconds": round(dt, 3)}
     if args.layer_report and rank == 0:
-        lib.ivosw_tune_set(b"STREAMS2", 0)                  # per-launch events: one stream, or the halves' kernels time each other
+        L.tune_set(b"STREAMS2", 0)                  # per-launch events: one stream, or the halves' kernels time each other
         lib.ivosw_profile_start()
         for _ in range(3):
             step()
-        lib.ivosw_tune_set(b"STREAMS2", 1)
+        L.tune_set(b"STREAMS2", 1)
         buf = ctypes.create_string_buffer(1 << 16)
         lib.ivosw_profile_report(buf, len(buf))
         t2, c2 = ctypes.c_double(0), ctypes.c_int(0)

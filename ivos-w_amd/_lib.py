@@ -102,6 +102,14 @@ def check(rc, what=""):
         raise RuntimeError(f"ivosw {what} failed ({rc}): {lib().ivosw_last_error().decode()}")
 
 
+def tune_set(key, value):
+    """ivosw_tune_set with its status checked: a switch that was silently not set would make an A/B test compare the default
+    with itself."""
+    if isinstance(key, str):
+        key = key.encode()
+    check(lib().ivosw_tune_set(key, int(value)), f"tune_set({key!r})")
+
+
 def dptr(t, dtype=None):
     """Raw device pointer of a contiguous CUDA tensor (raises for CPU tensors: no fallback)."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda:

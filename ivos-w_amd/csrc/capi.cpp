@@ -35,36 +35,55 @@ DeviceScope::~DeviceScope() {
 }  // namespace ivosw
 
 namespace ivosw {
-// Tunables: small fixed table, looked up by name.  Not thread-safe against concurrent ivosw_tune_set (tuning/test hook).
-struct Tunable { char key[32]; int value; };
-static Tunable g_tun[32];
+// Tunables: fixed table, looked up by name.  Not thread-safe against concurrent ivosw_tune_set (tuning/test hook).
+// The sources read 47 distinct keys (grep tune_get); the table holds every one of them set at once plus a cache entry per key
+// for the environment default (IVOSW_TUNE_<KEY> is read ONCE per key and process: a forward pass asks for ~40 keys).
+struct Tunable { char key[32]; int value; bool set, env_read, env_has; };
+constexpr int kMaxTunables = 160;
+static_assert(kMaxTunables >= 3 * 47, "the tunables table must hold every key the sources read, with room to grow");
+static Tunable g_tun[kMaxTunables];
 static int g_ntun = 0;
 
-static Tunable* tune_find(const char* key) {
+static Tunable* tune_find(const char* key, bool create) {
     for (int i = 0; i < g_ntun; ++i)
         if (strcmp(g_tun[i].key, key) == 0) return &g_tun[i];
-    return nullptr;
+    if (!create || g_ntun >= kMaxTunables || strlen(key) >= sizeof(g_tun[0].key)) return nullptr;
+    Tunable* t = &g_tun[g_ntun];
+    strcpy(t->key, key);
+    t->value = 0;
+    t->set = t->env_read = t->env_has = false;
+    ++g_ntun;                                        // published last: a concurrent reader sees a complete entry or none
+    return t;
 }
 
 int tune_get(const char* key, int dflt) {
-    if (Tunable* t = tune_find(key)) return t->value;
-    char env[64];
-    snprintf(env, sizeof(env), "IVOSW_TUNE_%s", key);
-    const char* e = getenv(env);
-    return e ? atoi(e) : dflt;
+    Tunable* t = tune_find(key, true);
+    if (!t) {                                        // table full / key too long: uncached environment lookup, still correct
+        char env[96];
+        snprintf(env, sizeof(env), "IVOSW_TUNE_%s", key);
+        const char* e = getenv(env);
+        return e ? atoi(e) : dflt;
+    }
+    if (t->set) return t->value;
+    if (!t->env_read) {
+        char env[64];
+        snprintf(env, sizeof(env), "IVOSW_TUNE_%s", key);
+        const char* e = getenv(env);
+        t->env_has = e != nullptr;
+        if (e) t->value = atoi(e);
+        t->env_read = true;
+    }
+    return t->env_has ? t->value : dflt;
 }
 }  // namespace ivosw
 
 extern "C" int ivosw_tune_set(const char* key, int value) {
     using namespace ivosw;
     IVOSW_REQUIRE(key && strlen(key) < sizeof(g_tun[0].key), "bad key");
-    Tunable* t = tune_find(key);
-    if (!t) {
-        IVOSW_REQUIRE(g_ntun < 32, "tunable table full");
-        t = &g_tun[g_ntun++];
-        strcpy(t->key, key);
-    }
+    Tunable* t = tune_find(key, true);
+    IVOSW_REQUIRE(t != nullptr, "tunable table full");
     t->value = value;
+    t->set = true;
     return IVOSW_OK;
 }
 

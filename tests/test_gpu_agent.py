@@ -108,7 +108,7 @@ def test_step_is_deterministic_and_independent_of_the_side_stream(dev):
     ref = None
     try:
         for streams in (1, 1, 0, 1, 0):
-            lib.ivosw_tune_set(b"DQN_STREAMS", streams)
+            L.tune_set(b"DQN_STREAMS", streams)
             for rep in range(3):
                 batch = synth.collate_np(tr, synth.minibatch_indices(rep, n=600, B=128, seed=5))
                 loss = agent.loss_and_grads(batch).cpu().numpy().copy()
@@ -119,7 +119,7 @@ def test_step_is_deterministic_and_independent_of_the_side_stream(dev):
                     np.testing.assert_array_equal(loss, ref[rep][0])
                     np.testing.assert_array_equal(g, ref[rep][1])
     finally:
-        lib.ivosw_tune_set(b"DQN_STREAMS", 1)
+        L.tune_set(b"DQN_STREAMS", 1)
 
 
 @pytest.mark.parametrize("B", [32, 128])
@@ -377,12 +377,12 @@ def test_alternative_kernel_paths_agree_with_the_default(dev, tun):
     g0 = agent.policy_net.flat_grad.cpu().numpy().copy()
     try:
         for k, v in tun.items():
-            lib.ivosw_tune_set(k.encode(), v)
+            L.tune_set(k.encode(), v)
         loss1 = agent.loss_and_grads(batch).item()
         g1 = agent.policy_net.flat_grad.cpu().numpy().copy()
     finally:
         for k in tun:
-            lib.ivosw_tune_set(k.encode(), 1)
+            L.tune_set(k.encode(), 1)
     np.testing.assert_allclose(loss1, loss0, rtol=1e-5)
     for k, (off, shp) in synth.brain_offsets().items():
         n = int(np.prod(shp))

@@ -142,9 +142,9 @@ def test_fused_bottleneck_matches_layerwise(dev, net16, net32):
     _, _, ttf, ttp = inputs(dev, 8, True)
     try:
         for nm in ("res2", "res3", "res4", "res5"):
-            lib.ivosw_tune_set(b"FUSE", 1)
+            L.tune_set(b"FUSE", 1)
             _, a = net16.forward_tap(ttf, ttp, nm)
-            lib.ivosw_tune_set(b"FUSE", 0)
+            L.tune_set(b"FUSE", 0)
             _, b = net16.forward_tap(ttf, ttp, nm)
             _, r = net32.forward_tap(ttf, ttp, nm)
             a, b, r = a.float().cpu().numpy(), b.float().cpu().numpy(), r.cpu().numpy()
@@ -153,13 +153,13 @@ def test_fused_bottleneck_matches_layerwise(dev, net16, net32):
             print(f"{nm}: fused vs fp32 {err_a:.3e}, layerwise vs fp32 {err_b:.3e}, fused vs layerwise {np.abs(a - b).max() / scale:.3e}")
             assert err_a < 3e-2 and err_a < 2.0 * err_b + 1e-3, nm    # as close to fp32 as the unfused bf16 path
             np.testing.assert_allclose(a.mean(), r.mean(), rtol=2e-3, err_msg=nm)
-        lib.ivosw_tune_set(b"FUSE", 1)
+        L.tune_set(b"FUSE", 1)
         sa = net16(ttf, ttp).cpu().numpy()
-        lib.ivosw_tune_set(b"FUSE", 0)
+        L.tune_set(b"FUSE", 0)
         sb = net16(ttf, ttp).cpu().numpy()
         np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
     finally:
-        lib.ivosw_tune_set(b"FUSE", 1)
+        L.tune_set(b"FUSE", 1)
 
 
 def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
@@ -173,14 +173,14 @@ def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
         _, _, ttf, ttp = inputs(dev, B, edge)
         for nm in ("res2", "res3", "res4", "res5"):
             try:
-                lib.ivosw_tune_set(b"FUSE_WIDE", 1)
+                L.tune_set(b"FUSE_WIDE", 1)
                 _, a = net16.forward_tap(ttf, ttp, nm)
                 sa = net16(ttf, ttp).cpu().numpy()
-                lib.ivosw_tune_set(b"FUSE_WIDE", 0)
+                L.tune_set(b"FUSE_WIDE", 0)
                 _, b = net16.forward_tap(ttf, ttp, nm)
                 sb = net16(ttf, ttp).cpu().numpy()
             finally:
-                lib.ivosw_tune_set(b"FUSE_WIDE", 1)
+                L.tune_set(b"FUSE_WIDE", 1)
             a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
             scale = np.abs(b).max()
             assert np.abs(a - b).max() <= 2e-2 * scale, (nm, np.abs(a - b).max() / scale)
@@ -199,14 +199,14 @@ def test_wide_1x1_conv_matches_tiled_kernel(dev, net16):
         _, _, ttf, ttp = inputs(dev, B, edge)
         for nm in ("res3", "res4", "res5"):
             try:
-                lib.ivosw_tune_set(b"WIDE1X1", 1)
+                L.tune_set(b"WIDE1X1", 1)
                 _, a = net16.forward_tap(ttf, ttp, nm)
                 sa = net16(ttf, ttp).cpu().numpy()
-                lib.ivosw_tune_set(b"WIDE1X1", 0)
+                L.tune_set(b"WIDE1X1", 0)
                 _, b = net16.forward_tap(ttf, ttp, nm)
                 sb = net16(ttf, ttp).cpu().numpy()
             finally:
-                lib.ivosw_tune_set(b"WIDE1X1", 1)
+                L.tune_set(b"WIDE1X1", 1)
             a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
             scale = np.abs(b).max()
             assert np.abs(a - b).max() <= 2e-2 * scale, (nm, np.abs(a - b).max() / scale)
@@ -226,16 +226,16 @@ def test_chained_res4_blocks_are_bit_identical_to_separate_launches(dev, net16):
         _, _, ttf, ttp = inputs(dev, B, edge)
         got = {}
         try:
-            lib.ivosw_tune_set(b"HALF16_MAX", 0)         # (launches this small would take the half-frame kernel, block by block)
+            L.tune_set(b"HALF16_MAX", 0)         # (launches this small would take the half-frame kernel, block by block)
             # chained + in place (default: blocks 2 .. 4 of the chain write y over their x) | chained, ping-pong buffers | one launch per block
             for key, run, inplace in (("inplace", 1, 1), ("chained", 1, 0), ("separate", 0, 0)):
-                lib.ivosw_tune_set(b"STAGE_RUN", run)
-                lib.ivosw_tune_set(b"INPLACE4", inplace)
+                L.tune_set(b"STAGE_RUN", run)
+                L.tune_set(b"INPLACE4", inplace)
                 got[key] = (net16.forward_tap(ttf, ttp, "res4")[1].clone(), net16.forward_tap(ttf, ttp, "res5")[1].clone(), net16(ttf, ttp).cpu().numpy())
         finally:
-            lib.ivosw_tune_set(b"STAGE_RUN", 1)
-            lib.ivosw_tune_set(b"INPLACE4", 1)
-            lib.ivosw_tune_set(b"HALF16_MAX", 96)
+            L.tune_set(b"STAGE_RUN", 1)
+            L.tune_set(b"INPLACE4", 1)
+            L.tune_set(b"HALF16_MAX", 96)
         for key in ("chained", "separate"):
             assert torch.equal(got["inplace"][0], got[key][0]) and torch.equal(got["inplace"][1], got[key][1]), key
             np.testing.assert_array_equal(got["inplace"][2], got[key][2])
@@ -250,27 +250,27 @@ def test_patch_resident_3x3_matches_per_tap_kernel(dev, net16):
     _, _, ttf, ttp = inputs(dev, 8, True)      # B=8: res5 uses the 4-frame tile (B % 4 == 0)
     try:
         for nm in ("res2", "res3", "res4", "res5"):
-            lib.ivosw_tune_set(b"PATCH3", 1)
+            L.tune_set(b"PATCH3", 1)
             _, a = net16.forward_tap(ttf, ttp, nm)
-            lib.ivosw_tune_set(b"PATCH3", 0)
+            L.tune_set(b"PATCH3", 0)
             _, b = net16.forward_tap(ttf, ttp, nm)
             a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
             scale = np.abs(b).max()
             assert np.abs(a - b).max() <= 2e-2 * scale, (nm, np.abs(a - b).max() / scale)
             np.testing.assert_allclose(a.mean(), b.mean(), rtol=2e-3, err_msg=nm)
-        lib.ivosw_tune_set(b"PATCH3", 1)
+        L.tune_set(b"PATCH3", 1)
         sa = net16(ttf, ttp).cpu().numpy()
-        lib.ivosw_tune_set(b"PATCH3", 0)
+        L.tune_set(b"PATCH3", 0)
         sb = net16(ttf, ttp).cpu().numpy()
         np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
         # B=3: res5's 4-frame tile does not apply (B % 4 != 0) -> the per-tap kernel serves it, results stay per-frame identical
         _, _, t3f, t3p = inputs(dev, 3, False)
-        lib.ivosw_tune_set(b"PATCH3", 1)
+        L.tune_set(b"PATCH3", 1)
         s3 = net16(t3f, t3p).cpu().numpy()
         np.testing.assert_allclose(s3.reshape(-1), np.load(os.path.join(os.path.dirname(__file__), "golden", "assess_forward.npz"))["B3_score"].reshape(-1),
                                    rtol=BF16_SCORE_RTOL)
     finally:
-        lib.ivosw_tune_set(b"PATCH3", 1)
+        L.tune_set(b"PATCH3", 1)
 
 
 def test_fused_stem_pool_matches_layerwise(dev, net16):
@@ -281,12 +281,12 @@ def test_fused_stem_pool_matches_layerwise(dev, net16):
     for B, edge in ((8, True), (3, False)):
         _, _, ttf, ttp = inputs(dev, B, edge)
         try:
-            lib.ivosw_tune_set(b"FUSE_STEM", 1)
+            L.tune_set(b"FUSE_STEM", 1)
             _, a = net16.forward_tap(ttf, ttp, "pool")
-            lib.ivosw_tune_set(b"FUSE_STEM", 0)
+            L.tune_set(b"FUSE_STEM", 0)
             _, b = net16.forward_tap(ttf, ttp, "pool")
         finally:
-            lib.ivosw_tune_set(b"FUSE_STEM", 1)
+            L.tune_set(b"FUSE_STEM", 1)
         a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
         assert a.shape == (B, 64, 64, 64) and (a >= 0).all()
         scale = np.abs(b).max()
@@ -432,10 +432,10 @@ def test_conv1_forwarding_through_res2_is_bit_identical(dev, net16):
         got = {}
         try:
             for mode in (1, 0):
-                lib.ivosw_tune_set(b"FWD2", mode)
+                L.tune_set(b"FWD2", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3")] + [net(ttf, ttp).clone()]
         finally:
-            lib.ivosw_tune_set(b"FWD2", 1)
+            L.tune_set(b"FWD2", 1)
         for a, b, nm in zip(got[1], got[0], ("res2", "res3", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
@@ -451,13 +451,13 @@ def test_snake_order_of_the_tower_launches_is_invisible(dev, net16):
         net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
         got = {}
         try:
-            lib.ivosw_tune_set(b"SNAKE_MIN", 1)          # (the default applies the order from 96 frames per stream)
+            L.tune_set(b"SNAKE_MIN", 1)          # (the default applies the order from 96 frames per stream)
             for mode in (1, 0):
-                lib.ivosw_tune_set(b"SNAKE", mode)
+                L.tune_set(b"SNAKE", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3", "res4", "res5")] + [net(ttf, ttp).clone()]
         finally:
-            lib.ivosw_tune_set(b"SNAKE", 1)
-            lib.ivosw_tune_set(b"SNAKE_MIN", 96)
+            L.tune_set(b"SNAKE", 1)
+            L.tune_set(b"SNAKE_MIN", 96)
         for a, b, nm in zip(got[1], got[0], ("res2", "res3", "res4", "res5", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
@@ -476,11 +476,11 @@ def test_depth_first_res3_and_uneven_halves_are_invisible(dev, net16):
     assert torch.equal(part, full)
     try:
         for k, v in ((b"DF3", 1), (b"SNAKE", 0), (b"INPLACE4", 0)):
-            lib.ivosw_tune_set(k, v)
+            L.tune_set(k, v)
         plain = net16(ttf, ttp).reshape(-1).clone()
     finally:
         for k, v in ((b"DF3", 2), (b"SNAKE", 1), (b"INPLACE4", 1)):
-            lib.ivosw_tune_set(k, v)
+            L.tune_set(k, v)
     assert torch.equal(plain, full)
 
 
@@ -499,10 +499,10 @@ def test_res2_stage_kernel_is_bit_identical_to_the_per_block_kernels(dev, net16)
         got = {}
         try:
             for mode in (1, 0):
-                lib.ivosw_tune_set(b"RES2_STAGE", mode)
+                L.tune_set(b"RES2_STAGE", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3")] + [net(ttf, ttp).clone()]
         finally:
-            lib.ivosw_tune_set(b"RES2_STAGE", 1)      # the default (assess.hip)
+            L.tune_set(b"RES2_STAGE", 1)      # the default (assess.hip)
         for a, b, nm in zip(got[1], got[0], ("res2", "res3", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
@@ -525,12 +525,12 @@ def test_two_stream_split_is_invisible_in_the_scores(dev, net16, net32):
         got = {}
         try:
             for mode in (1, 0, 1):
-                lib.ivosw_tune_set(b"STREAMS2", mode)
+                L.tune_set(b"STREAMS2", mode)
                 a = net16(ttf, ttp).clone()
                 b = net16(ttf.flip(0).contiguous(), ttp.flip(0).contiguous()).clone()      # immediately after, same stream
                 got.setdefault(mode, []).append((a, b))
         finally:
-            lib.ivosw_tune_set(b"STREAMS2", 1)
+            L.tune_set(b"STREAMS2", 1)
         for a, b in got[1]:
             assert torch.equal(a, got[0][0][0]) and torch.equal(b, got[0][0][1]), B
             assert torch.equal(a, b.flip(0)), B
@@ -540,10 +540,10 @@ def test_two_stream_split_is_invisible_in_the_scores(dev, net16, net32):
     try:
         f = {}
         for mode in (1, 0):
-            lib.ivosw_tune_set(b"STREAMS2", mode)
+            L.tune_set(b"STREAMS2", mode)
             f[mode] = net32(ttf, ttp).clone()
     finally:
-        lib.ivosw_tune_set(b"STREAMS2", 1)
+        L.tune_set(b"STREAMS2", 1)
     assert torch.equal(f[1], f[0])
     # ... and of the batch SIZE, multiples of 4 or not (res5's patch-resident 3x3 packs four 8x8 frames per tile: with B % 4 != 0
     # the whole launch used to fall back to the per-tap kernel, another summation order): every frame of a 150- / 67-frame
@@ -559,12 +559,12 @@ def test_two_stream_split_is_invisible_in_the_scores(dev, net16, net32):
     ttf = tf8.repeat(7, 1, 1, 1)[:n].contiguous()
     all_p = torch.stack([torch.roll(tp8.repeat(7, 1, 1)[:n], shifts=o, dims=0) for o in range(O + 1)], 1).contiguous()   # [n, O+1, H, W]
     try:
-        lib.ivosw_tune_set(b"STREAMS2", 1)
+        L.tune_set(b"STREAMS2", 1)
         s1 = net16.forward_objects(ttf, all_p, O).clone()
-        lib.ivosw_tune_set(b"STREAMS2", 0)
+        L.tune_set(b"STREAMS2", 0)
         s0 = net16.forward_objects(ttf, all_p, O).clone()
     finally:
-        lib.ivosw_tune_set(b"STREAMS2", 1)
+        L.tune_set(b"STREAMS2", 1)
     assert torch.equal(s1, s0)
 
 
@@ -617,10 +617,10 @@ def test_res3_small_tile_kernel_is_bit_identical(dev, net16):
         got = {}
         try:
             for mode in (1, 0):
-                lib.ivosw_tune_set(b"HALO128S", mode)
+                L.tune_set(b"HALO128S", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, "res3")[1].clone(), net(ttf, ttp).clone()]
         finally:
-            lib.ivosw_tune_set(b"HALO128S", 0)
+            L.tune_set(b"HALO128S", 0)
         for a, b, nm in zip(got[1], got[0], ("res3", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
@@ -637,9 +637,9 @@ def test_res4_half_frame_kernel_is_bit_identical(dev, net16):
         got = {}
         try:
             for mode in (96, 0):
-                lib.ivosw_tune_set(b"HALF16_MAX", mode)
+                L.tune_set(b"HALF16_MAX", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, "res4")[1].clone(), net(ttf, ttp).clone()]
         finally:
-            lib.ivosw_tune_set(b"HALF16_MAX", 96)
+            L.tune_set(b"HALF16_MAX", 96)
         for a, b, nm in zip(got[96], got[0], ("res4", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
