@@ -3,7 +3,7 @@
 weights/inputs of ``ivos_w_amd.synth`` and records the reference's own outputs as small .npz/.json
 fixtures next to this file.  The fixtures are data; no reference source travels.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py [brain] [dqn] [assess] [replay] [glue]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_goldens.py [brain] [dqn] [assess] [replay] [glue] [action] [seg] [misc]
 """
 import json
 import os
@@ -377,8 +377,70 @@ def make_action():
     print("agent_action.json", sum(c["random"] for c in out["calls"]), "random of", len(out["calls"]))
 
 
+# ----------------------------------------------------------------------------- seg: utils/utils_manet.py:59-163 (get_results)
+def make_seg():
+    """Runs the REFERENCE's get_results (imported from /root/reference/utils/utils_manet.py) on the CPU with the deterministic
+    stand-in model of tests/golden/scenarios.py.  Shims beyond Appendix D: `davisinteractive.dataset.davis` (the module imports
+    `Davis` from it, :6; unused by get_results), `config` (a module whose `cfg.KNNS` the propagation calls read, :101) and
+    `torch.Tensor.cuda` = identity for the duration of the calls (`prev_label = prev_label.cuda()`, :90, :123)."""
+    from tests.golden import scenarios as sc
+    ddd = types.ModuleType("davisinteractive.dataset.davis")
+    ddd.Davis = sys.modules["davisinteractive.dataset"].Davis
+    sys.modules["davisinteractive.dataset.davis"] = ddd
+    cfgmod = types.ModuleType("config")
+    cfgmod.cfg = AD(KNNS=sc.SEG_KNNS)
+    had = sys.modules.get("config")
+    sys.modules["config"] = cfgmod
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        from utils import utils_manet as ref
+        assert ref.__file__.startswith(REF), ref.__file__
+        out = {}
+        for name in sc.SEG_CASES:
+            model, kw = sc.seg_case(name, torch.device("cpu"))
+            store = {}
+            with torch.no_grad():
+                fm, ap = ref.get_results(model, kw["ref_frame_embedding"], kw["scribble_label"], kw["prev_label"], kw["eval_global_map_tmp_dic"],
+                                         kw["local_map_dics"], kw["n_interaction"], kw["sequence"], kw["obj_nums"], kw["next_frame"],
+                                         kw["first_scribble"], kw["h"], kw["w"], store, kw["total_frame_num"], kw["embedding_memory"])
+            # the stand-in's logits are smooth: the two best upsampled classes never come within 1e-4 of each other, so the label
+            # maps of an implementation that agrees to ~1e-6 must be IDENTICAL (recorded so the tests may rely on it)
+            top2 = torch.topk(torch.log(ap), 2, dim=1).values
+            out[f"{name}.min_top2_gap"] = np.array(float((top2[:, 0] - top2[:, 1]).min()))
+            out.update(sc.seg_record(name, fm, ap, store, model.calls))
+            print(name, tuple(fm.shape), tuple(ap.shape), "min top-2 gap", float(out[f"{name}.min_top2_gap"]), "calls", model.calls[:3])
+    finally:
+        torch.Tensor.cuda = real_cuda
+        if had is None:
+            sys.modules.pop("config", None)
+        else:
+            sys.modules["config"] = had
+    np.savez_compressed(os.path.join(HERE, "seg_get_results.npz"), **out)
+    print("seg_get_results.npz", os.path.getsize(os.path.join(HERE, "seg_get_results.npz")), "bytes")
+
+
+# ----------------------------------------------------------------------------- misc: utils/misc.py:11-115
+def make_misc():
+    """Runs the checkpoint / meter / seed scenarios of tests/golden/scenarios.py against the REFERENCE's utils/misc.py.  Shims: the
+    empty `cv2` of Appendix D and `davisinteractive.metrics.jaccard` with the two names the module imports (:8; only
+    sequence_metric, which is not recorded here, calls them)."""
+    import tempfile
+    from tests.golden import scenarios as sc
+    dm, dmj = types.ModuleType("davisinteractive.metrics"), types.ModuleType("davisinteractive.metrics.jaccard")
+    dmj.batched_f_measure = dmj.batched_jaccard = None
+    dm.jaccard = dmj
+    sys.modules["davisinteractive.metrics"], sys.modules["davisinteractive.metrics.jaccard"] = dm, dmj
+    from utils import misc as ref
+    assert ref.__file__.startswith(REF), ref.__file__
+    with tempfile.TemporaryDirectory() as tmp:
+        rec = sc.misc_scenarios(ref, tmp)
+    json.dump(rec, open(os.path.join(HERE, "misc_fixtures.json"), "w"), indent=1)
+    print("misc_fixtures.json", len(rec), "scenarios")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["brain", "dqn", "assess", "replay", "glue", "action"]
+    which = sys.argv[1:] or ["brain", "dqn", "assess", "replay", "glue", "action", "seg", "misc"]
     os.chdir("/tmp")
     install_shims()
     torch.set_num_threads(8)

@@ -112,6 +112,21 @@ def test_checkpoint_helpers_roundtrip(tmp_path):
     assert misc.load_network_checkpoint(str(tmp_path / "nope.pt"), encoder=None) is False
 
 
+def test_checkpoint_helpers_vs_reference_golden(tmp_path, golden_dir):
+    """The checkpoint / meter / seed helpers against the REFERENCE's utils/misc.py:11-115 run in the build container on the same
+    scenarios (tests/golden/scenarios.misc_scenarios, recorded by make_goldens.py misc): return values (None / 1 / -1, True /
+    False), the key rewrites ('module.' stripped by k[7:] whenever 'module' occurs ANYWHERE in the key, 'encoder.' put in front of
+    video_match 'base' keys, 'module.' added only when str(device) == 'cuda' resp. device == 'gpu'), the strict flag passed through,
+    what the save helpers leave in their files (the un-stripped state_dict), what is printed, and which loader swallows a failing
+    load_state_dict (the agent's) and which does not (the network's)."""
+    from tests.golden import scenarios as sc
+    want = json.load(open(os.path.join(golden_dir, "misc_fixtures.json")))
+    got = json.loads(json.dumps(sc.misc_scenarios(misc, str(tmp_path))))
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k] == want[k], (k, got[k], want[k])
+
+
 def test_assessnet_checkpoint_roundtrip(tmp_path):
     from ivos_w_amd.models.assessment import AssessNet
     a, b = AssessNet(), AssessNet()

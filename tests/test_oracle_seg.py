@@ -50,3 +50,23 @@ def test_epilogue_is_the_reference_ops():
     np.testing.assert_array_equal(up[:, :, 0, 0].numpy(), x[:, :, 0, 0].numpy())
     np.testing.assert_array_equal(up[:, :, -1, -1].numpy(), x[:, :, -1, -1].numpy())
     np.testing.assert_array_equal(lab.numpy(), up.argmax(1).numpy())
+
+
+def test_oracle_get_results_vs_reference_golden(golden_dir):
+    """oracle/seg_oracle.get_results against what the REFERENCE's get_results (utils/utils_manet.py:59-163, imported in the
+    build container by tests/golden/make_goldens.py seg) returned for the same stand-in model: same torch CPU kernels, so the
+    probabilities are equal bit for bit, and so are the label maps, the call order, the labels handed to the next propagation
+    step (they steer the stand-in's logits) and prev_label_storage."""
+    import os
+    from tests.golden import scenarios as sc
+    fx = np.load(os.path.join(golden_dir, "seg_get_results.npz"))
+    for name in sc.SEG_CASES:
+        model, kw = sc.seg_case(name, torch.device("cpu"))
+        store = {}
+        with torch.no_grad():
+            fm, ap = so.get_results(model, prev_label_storage=store, knns=sc.SEG_KNNS, **kw)
+        got = sc.seg_record(name, fm, ap, store, model.calls)
+        for k, v in got.items():
+            np.testing.assert_array_equal(v, fx[k], err_msg=k)
+        assert bool(fx[f"{name}.final_is_float32"]) and bool(fx[f"{name}.storage_is_int64"]) and bool(fx[f"{name}.storage_equals_final"])
+        assert fx[f"{name}.calls"][0, 0] == 0 and (fx[f"{name}.calls"][1:, 2] == sc.SEG_KNNS).all()      # cfg.KNNS reaches every propagation call
