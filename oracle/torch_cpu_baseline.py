@@ -58,8 +58,9 @@ class TorchDQN:
         self.gamma = torch.tensor(gamma, dtype=torch.float32)
         self.update_rate = update_rate
 
-    def update(self, batch, coin):
-        """One Agent.update_agent on a collated minibatch (synth.collate_np layout); returns the loss."""
+    def loss_and_grads(self, batch):
+        """Forward + backward of Agent.update_agent (models/agent.py:103-160) up to, and without, the clamp: (loss tensor, nothing
+        stepped); gradients are left in the policy parameters' .grad."""
         B = len(batch["action"])
         col = lambda k: torch.as_tensor(np.asarray(batch[k])).reshape(B, -1).float()
         state = torch.stack([col("old_state_iou"), col("annotated_frames")], 2)
@@ -76,6 +77,15 @@ class TorchDQN:
         loss = F.mse_loss(q_sa, y_step) + F.mse_loss(q_sa, y_done)
         self.opt.zero_grad()
         loss.backward()
+        return loss
+
+    def grads(self):
+        """{state_dict key: fp32 gradient} after loss_and_grads."""
+        return {k: p.grad.detach().numpy().copy() for k, p in self.policy.named_parameters()}
+
+    def update(self, batch, coin):
+        """One Agent.update_agent on a collated minibatch (synth.collate_np layout); returns the loss."""
+        loss = self.loss_and_grads(batch)
         for p in self.policy.parameters():
             p.grad.data.clamp_(-1, 1)
         self.opt.step()
