@@ -108,7 +108,8 @@ int ivosw_p2p_allreduce(const float* grads, float* out, int n, int rank, int wor
 /* ivosw_p2p_allreduce followed by ivosw_clamp_adam(grad_scale = 1/world) as TWO launches: push, then wait + rank-ordered sum + clamp
  * + Adam (the reference's clamp / optim.Adam step, models/agent.py:157-160, on the gradient averaged over the ranks).  grads_out
  * (NULL allowed, may alias grads) receives the summed gradient; `step` is the 1-based Adam step.  On a timeout nothing is updated
- * and the arena's error word is set (ivosw_p2p_error).                                                                        */
+ * (one verdict for the whole grid: workgroup 0 alone declares it) and the arena's error word is set (ivosw_p2p_error); once the
+ * word is set every later call returns without touching its outputs until the arena is re-created.                                                                        */
 int ivosw_p2p_allreduce_clamp_adam(const float* grads, float* grads_out, int n, int rank, int world, void* const* arenas,
                                    unsigned epoch, int timeout_ms, float* params, float* exp_avg, float* exp_avg_sq, int step,
                                    float lr, float beta1, float beta2, float eps, float weight_decay, float clamp,

@@ -99,18 +99,21 @@ static Plan make_plan(int dtype) {
 }
 
 // weights of the res2 stage kernel (res2_stage.hip) out of the packed bf16 arena
+// A fragment copy the plan does not hold has offset 0: its pointer stays NULL (base + 0 would silently be the first weights of the
+// arena), which is what res2_stage_ok() looks at before the per-block kernels / the probe's error take over.
 static Res2StageArgs res2_stage_args(const Plan& P, const char* base) {
     Res2StageArgs q{};
-    q.zeros = base + P.zero_off;
+    auto at = [&](size_t off) -> const void* { return off ? base + off : nullptr; };
+    q.zeros = at(P.zero_off);
     for (int b = 0; b < 3; ++b) {
         const BlockPlan& bp = P.blocks[b];
         const BlockPlan& nx = P.blocks[b + 1];
-        q.fb[b] = base + bp.f2_off; q.bb[b] = reinterpret_cast<const float*>(base + P.convs[bp.c2].b_off);
-        q.fc[b] = base + (b == 0 ? bp.cat_fw_off : bp.f3_off);
-        q.bc[b] = reinterpret_cast<const float*>(base + (b == 0 ? bp.cat_b_off : P.convs[bp.c3].b_off));
-        q.fd[b] = base + (b == 2 ? nx.fwd1_off : nx.f1_off); q.bd[b] = reinterpret_cast<const float*>(base + P.convs[nx.c1].b_off);
+        q.fb[b] = at(bp.f2_off); q.bb[b] = reinterpret_cast<const float*>(base + P.convs[bp.c2].b_off);
+        q.fc[b] = at(b == 0 ? bp.cat_fw_off : bp.f3_off);
+        q.bc[b] = static_cast<const float*>(b == 0 ? at(bp.cat_b_off) : base + P.convs[bp.c3].b_off);
+        q.fd[b] = at(b == 2 ? nx.fwd1_off : nx.f1_off); q.bd[b] = reinterpret_cast<const float*>(base + P.convs[nx.c1].b_off);
     }
-    q.fa0 = base + P.blocks[0].f1_off; q.ba0 = reinterpret_cast<const float*>(base + P.convs[P.blocks[0].c1].b_off);
+    q.fa0 = at(P.blocks[0].f1_off); q.ba0 = reinterpret_cast<const float*>(base + P.convs[P.blocks[0].c1].b_off);
     return q;
 }
 
@@ -432,7 +435,6 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     q.ds = 1; q.fc = base + bp.cat_fw_off; q.bc = reinterpret_cast<const float*>(base + bp.cat_b_off);
                 }
                 q.B = nb; q.H = hw; q.W = hw; q.Cin = c1.Cin; q.Cmid = c1.Cout;
-                q.rev = next_dir();
                 if (s == 0 && fwd2) {
                     // t1 ping-pong: b0 -> m2 -> b1 -> ds -> b2 -> m1 (res3's t1 for the frames of the enclosing res3 chunk)
                     const BlockPlan& nx = P.blocks[first_blk[0] + b + 1];          // the next block (res3's first after b == 2)
@@ -473,6 +475,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     x = out;
                     break;
                 }
+                q.rev = next_dir();                  // (after the depth-first branch, which takes a direction per launch of its own)
                 if (bp.ds < 0 && bneck_wide_fusable(q) && bneck_stage_fusable(q) && b + 1 < nblk[s]) {
                     // the rest of the stage is identity blocks of this shape: chain them inside one launch
                     BneckStageArgs sa{};

@@ -67,26 +67,41 @@ __global__ __launch_bounds__(1024) void p2p_push_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(1024) void p2p_reduce_kernel(float* __restrict__ out, int n, int world, void* arena, unsigned epoch,
-                                                          unsigned long long timeout_ticks) {
-    P2pHeader* h = static_cast<P2pHeader*>(arena);
-    const int parity = epoch & 1;
+// Wait for the `world` flags of this epoch.  The verdict is GRID-WIDE (with one deadline per workgroup, a peer
+// arriving near it let some workgroups apply their slice of clamp + Adam while others returned): only workgroup 0 declares a
+// timeout (it sets the arena's error word); every other workgroup spins until it sees all flags — then proceeds only if the
+// error word is still clear — or until it sees the error word.  Flags are monotonic within an epoch, so whenever any workgroup
+// saw them all before workgroup 0's deadline, workgroup 0 sees them too and never declares; if it declared first, latecomers find
+// the word set.  Either every workgroup applies or none does.  (A second bound of 2 x the timeout keeps a workgroup from spinning
+// forever should workgroup 0 never run; it sets the word too.)
+__device__ __forceinline__ bool p2p_wait_all(P2pHeader* h, int world, int parity, unsigned epoch, unsigned long long timeout_ticks) {
     __shared__ int bad;
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
     if ((int)threadIdx.x < world) {                          // lane s waits for rank s
         const unsigned long long t0 = wall_clock64();
+        const unsigned long long limit = blockIdx.x == 0 ? timeout_ticks : 2 * timeout_ticks;
         while (__hip_atomic_load(&h->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            if (wall_clock64() - t0 > timeout_ticks) { bad = 1; break; }
+            if (wall_clock64() - t0 > limit || __hip_atomic_load(&h->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
             __builtin_amdgcn_s_sleep(8);
         }
     }
     __syncthreads();
+    if (!bad && threadIdx.x == 0 && __hip_atomic_load(&h->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = 1;
+    __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope: nothing cached from the slots' previous contents
     if (bad) {
         if (threadIdx.x == 0) atomicExch(&h->error, 1u);
-        return;
+        return false;
     }
+    return true;
+}
+
+__global__ __launch_bounds__(1024) void p2p_reduce_kernel(float* __restrict__ out, int n, int world, void* arena, unsigned epoch,
+                                                          unsigned long long timeout_ticks) {
+    P2pHeader* h = static_cast<P2pHeader*>(arena);
+    const int parity = epoch & 1;
+    if (!p2p_wait_all(h, world, parity, epoch, timeout_ticks)) return;
     const int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     float4 s = *reinterpret_cast<const float4*>(p2p_slot(arena, world, n, parity, 0) + i4);
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(1024) void p2p_reduce_kernel(float* __restrict__ ou
 
 // The same wait + rank-ordered sum, with clamp + Adam applied to the sum as it is formed ("every GPU sums 8 slots
 // locally inside the clamp_adam kernel"): the summed gradient never makes a round trip through HBM and the data-parallel step
-// loses a launch.  gout (may be NULL) receives the summed, unscaled gradient.  On a timeout NOTHING is updated and the error word
+// loses a launch.  gout (may be NULL) receives the summed, unscaled gradient.  On a timeout NOTHING is updated (the verdict is grid-wide: p2p_wait_all) and the error word
 // is set: the host raises (ivos_w_amd.parallel), replicas cannot drift apart silently.
 __global__ __launch_bounds__(1024) void p2p_reduce_clamp_adam_kernel(float* __restrict__ gout, int n, int world, void* arena, unsigned epoch,
                                                                      unsigned long long timeout_ticks, float* __restrict__ p,
@@ -109,22 +124,7 @@ __global__ __launch_bounds__(1024) void p2p_reduce_clamp_adam_kernel(float* __re
                                                                      float clampv, float gscale) {
     P2pHeader* h = static_cast<P2pHeader*>(arena);
     const int parity = epoch & 1;
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
-    __syncthreads();
-    if ((int)threadIdx.x < world) {
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(&h->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            if (wall_clock64() - t0 > timeout_ticks) { bad = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    if (bad) {
-        if (threadIdx.x == 0) atomicExch(&h->error, 1u);
-        return;
-    }
+    if (!p2p_wait_all(h, world, parity, epoch, timeout_ticks)) return;
     const int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     float4 s = *reinterpret_cast<const float4*>(p2p_slot(arena, world, n, parity, 0) + i4);

@@ -425,6 +425,8 @@ def run_eval_real(cfg, backbone, device):
                 next_frame = first_frame = annotated[0]
                 seen_seq[sequence] = seen_seq.get(sequence, 0) + 1
                 if sequence not in frames_of:                  # decoded once per sequence: also the key of the device frame cache
+                    frames_of.clear()                          # davisinteractive serves a sequence's samples consecutively: keep ONE decoded
+                                                               # video (0.35 GB of fp32 at 480p), as the reference holds one all_F — not the whole set
                     jdir = os.path.join(root, "JPEGImages", "480p", sequence)
                     frames_of[sequence] = torch.from_numpy(np.ascontiguousarray(np.stack(
                         [np.asarray(cv2.imread(os.path.join(jdir, f)), dtype=np.float32)[:, :, [2, 1, 0]] / 255. for f in sorted(os.listdir(jdir))],

@@ -52,7 +52,37 @@ for si, s0 in enumerate(start):
             if used & pr:
                 bad += 1
                 if bad <= 12: print(name[-40:], "line", i - s0, ":", l[:100], "touches pending", sorted(pr)[:4])
-    print(name, "suspicious:", bad, "late scalar loads:", smem_late)
-    total = globals().get("total", 0) + bad + smem_late
+    # The prologue's counted VMEM wait (res2_stage.hip: wait_vmcnt<21> between the halo's LDS-DMA and the first barrier) is only right
+    # while EXACTLY that many vector-memory instructions sit between the last halo DMA and the wait: with fewer (loads merged, sunk or
+    # CSE'd by another hipcc) the barrier would release before the halo has landed.  Check the first counted wait behind an LDS-DMA.
+    vm_bad = 0
+    if "res2_stage" in name:
+        last_dma, n_vmem, checked = None, 0, False
+        for i in range(s0, e0):
+            l = lines[i].strip()
+            if not l or l.startswith(";") or l.startswith("."): continue
+            op = l.split()[0]
+            is_dma = (op.startswith("global_load_lds") or (op.startswith("buffer_load") and " lds" in l))
+            if is_dma:
+                last_dma, n_vmem = i, 0
+                continue
+            if op.startswith(("global_load", "buffer_load", "global_store", "buffer_store", "global_atomic", "flat_")):
+                n_vmem += 1
+                continue
+            m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", l)
+            if m and last_dma is not None:
+                n = int(m.group(1))
+                if n != 0 and n != n_vmem:
+                    vm_bad += 1
+                    print(name[-40:], "line", i - s0, ":", l[:60], "but", n_vmem, "vector-memory instructions follow the last LDS-DMA")
+                checked = True
+                break
+            if op == "s_barrier":
+                break
+        if not checked:
+            vm_bad += 1
+            print(name[-40:], ": no s_waitcnt vmcnt between the halo LDS-DMA and the first barrier")
+    print(name, "suspicious:", bad, "late scalar loads:", smem_late, "prologue vmcnt mismatches:", vm_bad)
+    total = globals().get("total", 0) + bad + smem_late + vm_bad
 
 sys.exit(1 if globals().get("total", 0) else 0)
