@@ -751,7 +751,29 @@ def bench_recommend(rank, dev, n=100, O=3, reps=8):
         reference_flow()
     t_ref = (time.perf_counter() - t0) / 3
     assert ref_pick == first, (ref_pick, first)
+    # evaluation-size launches: what recommend_frame issues per interaction is ONE forward over frames x objects units
+    # (utils/utils_agent.py:111-122), 50 - 300 units, not the 256-frame headline batch.  Whole-forward wall time (front end included)
+    # by HIP events, video and masks resident; frac = units x 10.779 GFLOP / time / 2.5 PFLOP/s.
+    eval_sizes = {}
+    fdev = all_F.to(dev)
+    for nf, no in ((100, 1), (100, 3), (70, 2)):
+        Fv, Pv = fdev[:nf].contiguous(), all_P[:nf, :no + 1].contiguous()
+        for _ in range(6):
+            net.forward_objects(Fv, Pv, no)
+        reps_e = 30
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps_e):
+            net.forward_objects(Fv, Pv, no)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / reps_e
+        units = nf * no
+        eval_sizes[f"{nf}x{no}"] = {"units": units, "ms": round(ms, 3), "units_per_s": round(units / ms * 1e3, 1),
+                                    "frac": round(units * GFLOP_PER_FRAME / ms / 1e6 / PEAK_BF16_TFLOPS, 4)}
     return {"metric": "recommend_frame_latency_ms", "frames": n, "objects": O, "first_call_ms": round(t_first * 1e3, 2),
+            "eval_sizes": eval_sizes,
             "value": round(t_next * 1e3, 2), "unit": "ms per interaction (video cached on the device)",
             "reference_data_movement_ms": round(t_ref * 1e3, 2),
             "note": "same kernels both ways; the reference re-uploads the 492 MB video and runs one forward per object every interaction (utils/utils_agent.py:114-119)",
