@@ -531,7 +531,7 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
         auto.run(steps)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
-        launches_per_step = (auto.graphed.launches - l0) / steps if auto.choice == "graph" else 10.0
+        launches_per_step = (auto.graphed.launches - l0) / steps if auto.choice == "graph" else 8.0
         launch_mode = {"mode": auto.choice, "requested": args.dqn_mode, "probe_us_per_step": {k: round(v, 1) for k, v in auto.probe_us.items()}}
     else:
         dt = None

@@ -138,6 +138,19 @@ int ivosw_replay_draw_gather(const float* old_iou, const float* new_iou, const f
                              float* state, float* new_state, int64_t* action_out, float* reward_step_out,
                              float* reward_done_out, ivosw_stream_t stream);
 
+/* One single-GPU training step of Agent.update_agent's loop (models/agent.py:128-160 minus the host coin of the target sync) as ONE
+ * call and EIGHT launches: ivosw_replay_draw_gather + ivosw_dqn_loss_grad + ivosw_clamp_adam_dev with the minibatch draw and gather
+ * folded into the encoder launch and the split-K slab reduction folded into clamp + Adam.  Same arithmetic, same orders of summation:
+ * parameters, Adam state, gradient arena, loss, idx_out / state / new_state / action_out / reward_*_out and both device counters end
+ * up bit-identical to the three separate calls.  `policy` is updated in place.  (When a tunable takes the step off the fused launch
+ * chain the entry runs the three calls itself.)                                                                                  */
+int ivosw_dqn_step_drawn(float* policy, const float* target, const float* old_iou, const float* new_iou, const float* annotated,
+                         const float* next_annotated, const int64_t* action, const float* reward_step, const float* reward_done,
+                         void* draw_state, int n, int B, int T, float gamma, int64_t* idx_out, float* state, float* new_state,
+                         int64_t* action_out, float* reward_step_out, float* reward_done_out, float* grads, float* loss, void* ws,
+                         size_t ws_bytes, float* exp_avg, float* exp_avg_sq, void* adam_state, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, float clamp, float grad_scale, ivosw_stream_t stream);
+
 /* ------------------------------------------------------------------ assessment front end ------ */
 /* Replaces (tp>0.5) + AssessNet.all2yxhw(scale=1.5) (models/assessment.py:165-166,110-161) with no D2H:
  * tp [B,H,W] fp32 -> yxhw [B,4] fp32 (y,x,h,w).  scratch: B*4 int32.                              */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "ivosw_replay_draw_state_bytes": (_sz, []),
     "ivosw_replay_draw_index": (C.c_ulonglong, [C.c_ulonglong, C.c_uint, C.c_uint, _i]),
     "ivosw_replay_draw_gather": (_i, [_p] * 8 + [_i, _i, _i] + [_p] * 6 + [_p]),
+    "ivosw_dqn_step_drawn": (_i, [_p] * 10 + [_i, _i, _i, _f] + [_p] * 9 + [_sz] + [_p] * 3 + [_f] * 7 + [_p]),
     "ivosw_mask_bbox": (_i, [_p, _i, _i, _i, _p, _p, _p]),
     "ivosw_roi_sample": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ivosw_assess_packed_bytes": (_sz, [_i]),

@@ -1021,8 +1021,9 @@ static bool fused_forward_ok(const FwdPass* f, int n) {
     if (n == 2) return tune_get("LSTM_MFMA", 1) && 2 * f[0].N >= 8 && 2 * f[1].N >= 8;   // the pair launch is the MFMA recurrence
     return true;
 }
-static void brain_forward_fused(const FwdPass* f, int n, int T, hipStream_t st) {
+static void brain_forward_fused(const FwdPass* f, int n, int T, hipStream_t st, const EncDraw* draw = nullptr) {
     EncGroup eg{};
+    if (draw) eg.dr = *draw;
     DecGroup dg{};
     int tiles[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
@@ -1284,18 +1285,21 @@ extern "C" size_t ivosw_dqn_ws_bytes(int B, int T) {
     return dqn_ws_floats(B, T) * sizeof(float);
 }
 
-extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, const float* state,
-                                   const float* new_state, const int64_t* action, const float* reward_step,
-                                   const float* reward_done, int B, int T, float gamma, float* grads, float* loss,
-                                   void* ws, size_t ws_bytes, ivosw_stream_t stream) {
+// draw != nullptr: the minibatch is drawn and gathered by the encoder launch (state / new_state / action / rewards are then OUTPUTS
+// of the step, written before anything reads them).  defer != nullptr: the fixed-order slab reduction is NOT launched; *defer
+// describes it and the caller folds it into clamp + Adam (ivosw_dqn_step_drawn).  Either needs the fused launch chain
+// (DQN_FUSED / DQN_GROUP / DQN_TAIL at their defaults): *folded says whether it was taken.
+static int dqn_loss_grad_impl(const float* policy, const float* target, const float* state, const float* new_state, const int64_t* action,
+                              const float* reward_step, const float* reward_done, int B, int T, float gamma, float* grads, float* loss,
+                              void* ws, size_t ws_bytes, ivosw_stream_t stream, const EncDraw* draw, ReduceGroup* defer, bool* folded) {
     IVOSW_REQUIRE(policy && target && state && new_state && action && reward_step && reward_done && grads && loss && ws,
                   "null pointer");
-    IVOSW_ON_DEVICE_OF(grads);
     IVOSW_REQUIRE(B > 0 && T > 0, "B and T must be positive");
     if (ws_bytes < ivosw_dqn_ws_bytes(B, T)) {
         set_error("ivosw_dqn_loss_grad: workspace %zu < %zu", ws_bytes, ivosw_dqn_ws_bytes(B, T));
         return IVOSW_ERR_WS;
     }
+    if (folded) *folded = false;
     hipStream_t st = as_stream(stream);
     const int rows = B * T;
     Arena ar(ws);
@@ -1339,6 +1343,9 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     // (host order matters: the policy chain is the critical path, so it is enqueued first)
     const FwdPass passes[2] = {{policy, new_state, state, 2 * B, B, &w.pol}, {target, new_state, nullptr, B, 0, &w.tgt}};
     const bool fused = fused_forward_ok(passes, 2);
+    const bool fold = (draw || defer) && fused && tune_get("DQN_GROUP", 1) && tune_get("DQN_TAIL", 1);
+    if ((draw || defer) && !fold) return IVOSW_OK;    // the caller runs the un-folded sequence instead (nothing was launched)
+    if (folded) *folded = fold;
     const float* q_np = w.pol.q;
     const float* q_s = w.pol.q + rows;
     const float* d1_s = w.pol.d1 + (size_t)rows * 128;
@@ -1346,7 +1353,7 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     GemmF32 g{};
     if (fused) {
         // both nets per launch, then head + decoder backward + dL/dh in one: 4 launches, one stream, no events
-        brain_forward_fused(passes, 2, T, st);
+        brain_forward_fused(passes, 2, T, st, draw);
         hipLaunchKernelGGL(head_fused_kernel, dim3(B), dim3(256), 0, st, policy, O_W3, O_W4, q_np, w.tgt.q, q_s, action, reward_step,
                            reward_done, B, T, gamma, d1_s, hs_s, w.dq, w.dd1c, w.w4term, w.hcc, w.dhc, loss, grads + O_B4);
     } else {
@@ -1491,7 +1498,8 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
         rg.slabs[3] = cs_b2; rg.out[3] = grads + O_B2; rg.n[3] = 128; rg.nslab[3] = CS;
         rg.slabs[4] = cs_b1; rg.out[4] = grads + O_B1; rg.n[4] = 128; rg.nslab[4] = CS;
         rg.slabs[5] = cs_w1; rg.out[5] = grads + O_W1; rg.n[5] = 256; rg.nslab[5] = CS;
-        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(512 * 128 / 256, 6), dim3(256), 0, st, rg);
+        if (defer) *defer = rg;
+        else hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(512 * 128 / 256, 6), dim3(256), 0, st, rg);
     } else {
         fork(2);
         hipLaunchKernelGGL(colsum_kernel, dim3(4), dim3(1024), 0, s2, w.w4term, B, 128, 128, grads + O_W4);
@@ -1518,6 +1526,122 @@ extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, con
     }
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
+}
+
+extern "C" int ivosw_dqn_loss_grad(const float* policy, const float* target, const float* state,
+                                   const float* new_state, const int64_t* action, const float* reward_step,
+                                   const float* reward_done, int B, int T, float gamma, float* grads, float* loss,
+                                   void* ws, size_t ws_bytes, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(grads, "null pointer");
+    IVOSW_ON_DEVICE_OF(grads);
+    return dqn_loss_grad_impl(policy, target, state, new_state, action, reward_step, reward_done, B, T, gamma, grads, loss, ws, ws_bytes,
+                              stream, nullptr, nullptr, nullptr);
+}
+
+// Clamp + Adam (clamp_adam_dev_kernel's expressions: same bits) with the step's split-K slab reduction folded in: an element of
+// a slabbed tensor is summed from its slabs ON LOAD in splitk_reduce_group_kernel's order (four interleaved partial sums over
+// z, eight loads in flight, (s0 + s1) + (s2 + s3)) and written to the gradient arena on the way, so the arena holds what the
+// separate reduction would have left there.  off[k] = element offset of slab set k in the arena.
+struct ReduceOffsets { int off[REDUCE_MAX]; };
+// One element per lane, 177 workgroups: the slabs (13.5 MB at B = 128, T = 25, fresh in L2) are pulled by the whole chip — with the
+// 45 workgroups of the 16-byte form the launch took 11 us, more than the reduction + update launches it replaces (5.3 + 5.1).
+__global__ __launch_bounds__(1024) void clamp_adam_dev_reduce_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                                     float* __restrict__ v, int n, AdamDevState* __restrict__ st, ReduceGroup rg,
+                                                                     ReduceOffsets ro, float lr, float beta1, float beta2, float eps, float wd,
+                                                                     float clampv, float gscale) {
+    const int step = st->step + 1;
+    const double b1t = ipow((double)beta1, step), b2t = ipow((double)beta2, step);
+    const float step_size = (float)((double)lr / (1.0 - b1t)), bc2_sqrt = (float)sqrt(1.0 - b2t);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        int w = -1;
+#pragma unroll
+        for (int k = 0; k < REDUCE_MAX; ++k)
+            if (rg.nslab[k] > 0 && i >= ro.off[k] && i < ro.off[k] + rg.n[k]) w = k;
+        float gi;
+        if (w >= 0) {
+            const float* sl = rg.slabs[w] + (i - ro.off[w]);
+            const size_t nn = rg.n[w];
+            const int ns = rg.nslab[w];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int z = 0;
+            for (; z + 8 <= ns; z += 8) {
+                float q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = sl[(size_t)(z + u) * nn];
+                s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3];
+                s0 += q[4]; s1 += q[5]; s2 += q[6]; s3 += q[7];
+            }
+            for (; z < ns; ++z) s0 += sl[(size_t)z * nn];
+            gi = (s0 + s1) + (s2 + s3);
+            g[i] = gi;
+        } else {
+            gi = g[i];
+        }
+        float mi = m[i], vi = v[i];
+        p[i] = clamp_adam_elem(gi, p[i], mi, vi, step_size, bc2_sqrt, beta1, beta2, eps, wd, clampv, gscale);
+        m[i] = mi; v[i] = vi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&st->ticket, 1u) == gridDim.x - 1) {
+            st->b1t = b1t; st->b2t = b2t; st->step = step; st->step_size = step_size; st->bc2_sqrt = bc2_sqrt;
+            atomicExch(&st->ticket, 0u);
+        }
+    }
+}
+
+extern "C" int ivosw_replay_draw_gather(const float* old_iou, const float* new_iou, const float* annotated, const float* next_annotated,
+                                        const int64_t* action, const float* reward_step, const float* reward_done, void* draw_state, int n,
+                                        int B, int T, int64_t* idx_out, float* state, float* new_state, int64_t* action_out,
+                                        float* reward_step_out, float* reward_done_out, ivosw_stream_t stream);
+extern "C" int ivosw_clamp_adam_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int n, void* adam_state, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, float clamp, float grad_scale,
+                                    ivosw_stream_t stream);
+
+extern "C" int ivosw_dqn_step_drawn(float* policy, const float* target, const float* old_iou, const float* new_iou, const float* annotated,
+                                    const float* next_annotated, const int64_t* action, const float* reward_step, const float* reward_done,
+                                    void* draw_state, int n, int B, int T, float gamma, int64_t* idx_out, float* state, float* new_state,
+                                    int64_t* action_out, float* reward_step_out, float* reward_done_out, float* grads, float* loss, void* ws,
+                                    size_t ws_bytes, float* exp_avg, float* exp_avg_sq, void* adam_state, float lr, float beta1, float beta2,
+                                    float eps, float weight_decay, float clamp, float grad_scale, ivosw_stream_t stream) {
+    IVOSW_REQUIRE(policy && target && old_iou && new_iou && annotated && next_annotated && action && reward_step && reward_done && draw_state &&
+                      idx_out && state && new_state && action_out && reward_step_out && reward_done_out && grads && loss && ws && exp_avg &&
+                      exp_avg_sq && adam_state,
+                  "null pointer");
+    IVOSW_ON_DEVICE_OF(grads);
+    IVOSW_REQUIRE(n > 0 && B > 0 && T > 0, "n, B and T must be positive");
+    const bool aligned = ((reinterpret_cast<uintptr_t>(policy) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+                           reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0;
+    bool folded = false;
+    if (aligned && tune_get("DQN_ONECALL", 1)) {
+        const EncDraw dr{old_iou, new_iou, annotated, next_annotated, action, reward_step, reward_done, static_cast<DrawState*>(draw_state), n, B, T,
+                         idx_out, state, new_state, action_out, reward_step_out, reward_done_out};
+        ReduceGroup rg{};
+        const int rc = dqn_loss_grad_impl(policy, target, state, new_state, action_out, reward_step_out, reward_done_out, B, T, gamma, grads, loss,
+                                          ws, ws_bytes, stream, &dr, &rg, &folded);
+        if (rc != IVOSW_OK) return rc;
+        if (folded) {
+            ReduceOffsets ro{};
+            for (int k = 0; k < REDUCE_MAX; ++k) ro.off[k] = rg.out[k] ? (int)(rg.out[k] - grads) : 0;
+            const int nprm = IVOSW_BRAIN_NPARAMS;
+            hipLaunchKernelGGL(clamp_adam_dev_reduce_kernel, dim3((nprm + 1023) / 1024), dim3(1024), 0, as_stream(stream), policy, grads,
+                               exp_avg, exp_avg_sq, nprm, static_cast<AdamDevState*>(adam_state), rg, ro, lr, beta1, beta2, eps, weight_decay,
+                               clamp, grad_scale);
+            IVOSW_CHECK_LAUNCH();
+            return IVOSW_OK;
+        }
+    }
+    // the un-folded sequence (a tunable moved the step off the fused launch chain): the same three entries the caller would have made
+    int rc = ivosw_replay_draw_gather(old_iou, new_iou, annotated, next_annotated, action, reward_step, reward_done, draw_state, n, B, T, idx_out,
+                                      state, new_state, action_out, reward_step_out, reward_done_out, stream);
+    if (rc == IVOSW_OK)
+        rc = ivosw_dqn_loss_grad(policy, target, state, new_state, action_out, reward_step_out, reward_done_out, B, T, gamma, grads, loss, ws,
+                                 ws_bytes, stream);
+    if (rc == IVOSW_OK)
+        rc = ivosw_clamp_adam_dev(policy, grads, exp_avg, exp_avg_sq, IVOSW_BRAIN_NPARAMS, adam_state, lr, beta1, beta2, eps, weight_decay, clamp,
+                                  grad_scale, stream);
+    return rc;
 }
 
 /* Tuning probe: subsequent fused forwards stamp s_memtime at four points of recurrence step T/2 per workgroup into ts

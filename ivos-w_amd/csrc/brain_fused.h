@@ -18,6 +18,7 @@
 // each weight is needed by ONE wave of the workgroup and goes from L2 straight into its registers (16-byte loads along K).
 // K order: lane (i, kq) of an MFMA step carries k = 16 c + 4 kq + step — A and B agree, which is all a contraction needs.
 #pragma once
+#include "adam.h"
 #include "common.h"
 
 namespace ivosw {
@@ -37,9 +38,25 @@ struct EncJob {
     float* e;           // [rows, 128], same
     int rows0, rows, keep_row;
 };
+// The minibatch DRAWN AND GATHERED by the encoder launch itself (ivosw_dqn_step_drawn: one link less in the step's launch chain
+// than ivosw_replay_draw_gather in front of it).  Row r of a job is frame r % T of sample r / T; the sample's replay row is the
+// draw of slot r / T (adam.h: draw_mix), its two input scalars come straight from the replay columns, and the policy job leaves
+// the gathered minibatch behind for the head / tail kernels and the caller.  ds == nullptr: rows come from EncJob::x / x2.
+struct EncDraw {
+    const float *old_iou, *new_iou, *ann, *nann;       // [n, T] replay columns
+    const int64_t* action;                              // [n]
+    const float *rstep, *rdone;
+    DrawState* ds;
+    int n, B, T;
+    int64_t* idx_out;                                   // [B] rows drawn
+    float *state, *new_state;                           // [B, T, 2]
+    int64_t* action_out;
+    float *rstep_out, *rdone_out;
+};
 struct EncGroup {
     EncJob j[2];
     int first1;         // first workgroup of job 1 (grid size when there is one job)
+    EncDraw dr;
 };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -67,9 +84,30 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncGroup grp, int o_w1, 
     // hides an L2 round trip): the tile's 96 input scalars, this wave's 32 x 128 slice of W2 (16 float4 per lane) and the
     // first K-chunk of its 128 x 128 slice of W_ih.
     float xv = 0.f;
+    unsigned draw_counter = 0;
+    if (grp.dr.ds) draw_counter = grp.dr.ds->counter;       // read before this workgroup's ticket (below): the last ticket advances it
     if (tid < FM * 2) {
-        const int row = min(r0 + (tid >> 1), jb.rows - 1);
-        xv = row < jb.rows0 ? jb.x[(size_t)row * 2 + (tid & 1)] : jb.x2[(size_t)(row - jb.rows0) * 2 + (tid & 1)];
+        const int row = min(r0 + (tid >> 1), jb.rows - 1), c = tid & 1;
+        if (grp.dr.ds) {
+            const EncDraw& d = grp.dr;
+            const bool second = row >= jb.rows0;            // policy job: rows [0, B T) = s' (new state), [B T, 2 B T) = s
+            const int rr = second ? row - jb.rows0 : row;
+            const int b = rr / d.T, t = rr - b * d.T;
+            const int64_t src = (int64_t)__umul64hi(draw_mix(d.ds->seed, draw_counter, (unsigned)b), (unsigned long long)d.n);
+            const float* col = second ? (c ? d.ann : d.old_iou) : (c ? d.nann : d.new_iou);
+            xv = col[(size_t)src * d.T + t];
+            if (which == 0 && r0 + (tid >> 1) < jb.rows) {
+                (second ? d.state : d.new_state)[(size_t)rr * 2 + c] = xv;
+                if (second && t == 0 && c == 0) {
+                    d.idx_out[b] = src;
+                    d.action_out[b] = d.action[src];
+                    d.rstep_out[b] = d.rstep[src];
+                    d.rdone_out[b] = d.rdone[src];
+                }
+            }
+        } else {
+            xv = row < jb.rows0 ? jb.x[(size_t)row * 2 + c] : jb.x2[(size_t)(row - jb.rows0) * 2 + c];
+        }
     }
     const int j1 = tid & 127;
     const float w10 = prm[o_w1 + 2 * j1], w11 = prm[o_w1 + 2 * j1 + 1], b1v = prm[o_b1 + j1];
@@ -172,6 +210,13 @@ __global__ __launch_bounds__(256) void enc_fused_kernel(EncGroup grp, int o_w1, 
                 }
             }
         FPROBE(5);
+    }
+    if (grp.dr.ds && tid == 0) {                     // the LAST workgroup to finish advances the draw counter (every workgroup read it at its start)
+        DrawState* ds = grp.dr.ds;
+        if (atomicAdd(&ds->ticket, 1u) == gridDim.x - 1) {
+            ds->counter = draw_counter + 1;
+            atomicExch(&ds->ticket, 0u);
+        }
     }
 }
 

@@ -48,18 +48,6 @@ __global__ void replay_gather_kernel(const float* __restrict__ old_iou, const fl
 // draw counter lives on the device and is advanced by the LAST workgroup of the launch (a ticket, as in clamp_adam_dev), so a
 // captured HIP graph replays a fresh minibatch each time with no host-side RNG launch in front of it (that launch and the
 // bubble it left before the graph cost ~9.5 us of a 204 us step).
-struct DrawState {
-    unsigned long long seed;
-    unsigned counter;
-    unsigned ticket;
-};
-static_assert(sizeof(DrawState) == 16, "DrawState layout (seed at byte 0, counter at byte 8)");
-__host__ __device__ inline unsigned long long draw_mix(unsigned long long seed, unsigned counter, unsigned slot) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)counter + 1) + 0xD1B54A32D192ED03ull * ((unsigned long long)slot + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
 __global__ void replay_draw_gather_kernel(const float* __restrict__ old_iou, const float* __restrict__ new_iou,
                                           const float* __restrict__ ann, const float* __restrict__ nann,
                                           const int64_t* __restrict__ action, const float* __restrict__ rstep,
@@ -117,17 +105,6 @@ __global__ void quality_state_kernel(const float* __restrict__ scores, int n_obj
     state[2 * f] = (float)q;
     state[2 * f + 1] = counts[f];
 }
-
-// Adam's step counter and bias corrections kept ON the device, so that a captured HIP graph of the DQN step replays
-// correctly: tick advances step, evaluates beta1^t / beta2^t in float64 and publishes step_size / sqrt(bc2).
-// Layout (32 bytes): the step counter is the int32 at byte 16; a caller resumes from host step k by writing k there.
-struct AdamDevState {
-    double b1t, b2t;
-    int step;
-    float step_size, bc2_sqrt;
-    unsigned ticket;     // byte 28: workgroups of the running clamp+Adam launch that have finished (0 between launches)
-};
-static_assert(sizeof(AdamDevState) == 32, "AdamDevState layout (step at byte 16, ticket at byte 28)");
 
 // Clamp + Adam with the step counter advanced by the SAME launch (a one-thread tick kernel in front of it cost a link of the
 // step's launch chain, ~5 us): every thread reads the counter k left by the previous launch and evaluates step k+1's bias

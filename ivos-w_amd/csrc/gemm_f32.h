@@ -4,6 +4,7 @@
 // N,K <= 512), so the tile is 64x64x64 with generic operand strides; wgrad shapes (small MxN, long K)
 // use split-K into slabs + a fixed-order reduce (deterministic, no atomics).
 #pragma once
+#include "adam.h"
 #include "common.h"
 #include <stdlib.h>
 
@@ -239,12 +240,6 @@ __global__ void splitk_reduce_kernel(const float* slabs, float* out, int n, int 
 }
 
 // the same for up to six slab sets in one launch (blockIdx.y = which)
-constexpr int REDUCE_MAX = 6;
-struct ReduceGroup {
-    const float* slabs[REDUCE_MAX];
-    float* out[REDUCE_MAX];
-    int n[REDUCE_MAX], nslab[REDUCE_MAX];
-};
 __global__ void splitk_reduce_group_kernel(ReduceGroup r) {
     const int w = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r.n[w]) return;

@@ -325,7 +325,7 @@ class CapturedDqnStep:
     Replaces ~40 host launches (170-250 us of enqueue per step) by one hipGraphLaunch.  The arithmetic is the eager path's:
     the same entry points are recorded, so results are bit-identical to ``Agent.loss_and_grads`` + ``optimizer.step``."""
 
-    def __init__(self, agent, replay, B, fused=True, draw_seed=None, steps=1, draw_state=None):
+    def __init__(self, agent, replay, B, fused=True, draw_seed=None, steps=1, draw_state=None, capture=True):
         """draw_seed: None = the caller writes the minibatch rows into ``self.idx`` before every launch; an integer = the rows
         are drawn INSIDE the graph (``ivosw_replay_draw_gather``, uniform with replacement from a device-side counter-based
         generator seeded with it), ``self.idx`` then holds the rows of the last launch.  draw_state: share another captured
@@ -354,11 +354,37 @@ class CapturedDqnStep:
             opt.dev_state()
         self._keys = (pn.flat.data_ptr(), tn.flat.data_ptr(), pn.flat_grad.data_ptr())
         self._hyper = self._hyper_now()          # lr / betas / eps / weight decay / clamp / grad_scale / gamma are baked into the graph
+        self._nbytes, self.graph, self.kernel_nodes, self._onecall_args = nbytes, None, None, None
+        if not capture:                          # capture=False: the same launches, enqueued plainly by launch() (LeanDqnLoop)
+            return
         torch.cuda.synchronize(dev)
         with L.Graph.capture(dev) as g:
-          for _ in range(self.steps):
+            self._enqueue()
+        self.graph = g
+        self.kernel_nodes = g.kernel_nodes
+
+    def _enqueue(self):
+        """The step's launches on the current stream (recorded when a capture is open)."""
+        agent, replay, B, fused = self.agent, self.replay, self.B, self.fused
+        dev = torch.device(agent.device)
+        lib, T, nbytes = L.lib(), replay.T, self._nbytes
+        pn, tn, opt = agent.policy_net, agent.target_net, agent.optimizer
+        for _ in range(self.steps):
             st = L.stream_ptr(dev)
             r = replay
+            if self.draw is not None and fused:
+                # draw + gather folded into the encoder launch, the slab reduction into clamp + Adam: 8 kernel nodes per step instead of 10
+                if self._onecall_args is None:   # every pointer and scalar is fixed for the life of the object (launch() checks): built once
+                    g_, os_ = opt.param_groups[0], opt.state
+                    self._onecall_args = (
+                        L.dptr(pn.flat), L.dptr(tn.flat), L.dptr(r.old_iou), L.dptr(r.new_iou), L.dptr(r.ann), L.dptr(r.next_ann),
+                        L.dptr(r.action), L.dptr(r.reward_step), L.dptr(r.reward_done), L.dptr(self.draw, torch.uint8), r.n, B, T,
+                        float(np.float32(agent.GAMMA)), L.dptr(self.idx), L.dptr(self.state), L.dptr(self.new_state), L.dptr(self.action),
+                        L.dptr(self.r_step), L.dptr(self.r_done), L.dptr(pn.flat_grad), L.dptr(self.loss), L.dptr(self.ws), nbytes,
+                        L.dptr(os_["exp_avg"]), L.dptr(os_["exp_avg_sq"]), L.dptr(os_["dev"]), g_["lr"], g_["betas"][0], g_["betas"][1],
+                        g_["eps"], g_["weight_decay"], g_["clamp"], opt.grad_scale)
+                L.check(lib.ivosw_dqn_step_drawn(*self._onecall_args, st), "dqn_step_drawn")
+                continue
             if self.draw is not None:
                 r.sample_drawn(B, self.draw, out=dict(idx=self.idx, state=self.state, new_state=self.new_state, action=self.action,
                                                       reward_step=self.r_step, reward_done=self.r_done))
@@ -373,8 +399,6 @@ class CapturedDqnStep:
                                             L.dptr(self.ws), nbytes, st), "dqn_loss_grad")
             if fused:
                 opt.enqueue_dev_step()
-        self.graph = g
-        self.kernel_nodes = g.kernel_nodes
 
     def _hyper_now(self):
         """What the captured launches bake in: gamma always (the loss); the optimizer's values only when clamp + Adam are part of
@@ -395,7 +419,10 @@ class CapturedDqnStep:
                                "the graph replays the captured values - build a new CapturedDqnStep")
         if self.fused:
             a.optimizer.dev_state()              # resync if an eager step ran in between
-        self.graph.launch()
+        if self.graph is not None:
+            self.graph.launch()
+        else:
+            self._enqueue()
         if self.fused:
             a.optimizer.note_dev_steps(self.steps)
         return self.loss
@@ -438,23 +465,21 @@ class GraphedDqnLoop:
 
 
 class LeanDqnLoop:
-    """The same loop from PLAIN launches out of preallocated buffers: draw + gather, loss + gradients (8 kernels), clamp + Adam,
-    coin — ten launches per step, no graph.  With the launch chain this short the host keeps ahead of the GPU (~190 us of GPU
+    """The same loop from PLAIN launches out of preallocated buffers (ivosw_dqn_step_drawn: encoder with the draw + gather, recurrence,
+    decoder, head, BPTT, two tail launches, clamp + Adam with the slab reduction — eight launches per step, no graph; ten before round 4).  With the launch chain this short the host keeps ahead of the GPU (~190 us of GPU
     work per step) and the step loses the bubble that separates two graph launches; on a loaded host the captured loop is the
     safer choice (``AutoDqnLoop`` measures).  Same arithmetic, same coin and minibatch streams: bit-identical to the other loops."""
 
     def __init__(self, agent, replay, B, draw_seed, draw_state=None):
         self.agent, self.replay, self.B = agent, replay, B
-        self.draw = draw_state if draw_state is not None else replay.draw_state(draw_seed)
-        self.bufs = None
+        self.step = CapturedDqnStep(agent, replay, B, fused=True, draw_seed=draw_seed, draw_state=draw_state, capture=False)
+        self.draw = self.step.draw
         self.syncs = 0
 
     def run(self, n):
         a, loss = self.agent, None
         for _ in range(n):
-            self.bufs = self.replay.sample_drawn(self.B, self.draw, out=self.bufs)
-            loss = a.loss_and_grads(self.bufs)
-            a.optimizer.step()
+            loss = self.step.launch()               # ivosw_dqn_step_drawn: eight plain launches, the step counters on the device
             if np.random.random() < a.update_rate:
                 a.sync_target()
                 self.syncs += 1

@@ -299,6 +299,43 @@ def test_device_side_minibatch_draw(dev):
         assert torch.equal(eager.policy_net.flat, cap.policy_net.flat), c
 
 
+def test_one_call_step_equals_the_three_calls(dev):
+    """ivosw_dqn_step_drawn (draw + gather inside the encoder launch, slab reduction inside clamp + Adam: 8 kernel nodes) against the
+    three entries it replaces (ivosw_replay_draw_gather, ivosw_dqn_loss_grad, ivosw_clamp_adam_dev: 10 nodes; tunable DQN_ONECALL=0
+    makes the entry run exactly those): after every one of 5 steps the rows drawn, the gathered minibatch, loss, gradient arena,
+    parameters, both Adam moments and the two device counters are identical bit for bit."""
+    from ivos_w_amd import _lib as L
+    from ivos_w_amd.models.agent import Agent, CapturedDqnStep
+    from ivos_w_amd.models.momory_pool import DeviceReplay, draw_indices
+    tr = synth.replay_transitions(n=3000, T=25, seed=11)
+    rp = DeviceReplay(tr, dev)
+    B, seed = 128, 0xABCDEF0123
+
+    def build(onecall):
+        L.tune_set(b"DQN_ONECALL", onecall)
+        a = Agent(dev, cfg())
+        load_brain(a.policy_net, 0)
+        load_brain(a.target_net, 1)
+        return a, CapturedDqnStep(a, rp, B, fused=True, draw_seed=seed)
+    try:
+        (a1, s1), (a0, s0) = build(1), build(0)
+    finally:
+        L.tune_set(b"DQN_ONECALL", 1)
+    assert (s1.kernel_nodes, s0.kernel_nodes) == (8, 10), (s1.kernel_nodes, s0.kernel_nodes)
+    for c in range(5):
+        s1.launch()
+        s0.launch()
+        np.testing.assert_array_equal(s1.idx.cpu().numpy(), draw_indices(seed, c, B, len(rp)))
+        for name in ("idx", "state", "new_state", "action", "r_step", "r_done", "loss"):
+            assert torch.equal(getattr(s1, name), getattr(s0, name)), (c, name)
+        assert torch.equal(a1.policy_net.flat_grad, a0.policy_net.flat_grad), c
+        assert torch.equal(a1.policy_net.flat, a0.policy_net.flat), c
+        for k in ("exp_avg", "exp_avg_sq", "dev"):
+            assert torch.equal(a1.optimizer.state[k], a0.optimizer.state[k]), (c, k)
+        assert torch.equal(s1.draw, s0.draw)
+    assert not torch.equal(a1.policy_net.flat, torch.from_numpy(synth.brain_flat(synth.brain_state_dict(0))).to(dev))
+
+
 def test_blocked_graph_loop_equals_the_step_by_step_loop(dev):
     """GraphedDqnLoop (8 steps per hipGraphLaunch when no target-sync coin of the block fires) against single-step launches with
     the coin after every step: same np.random coin stream, same device-side minibatch stream -> identical parameters, target
