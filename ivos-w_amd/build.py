@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libivosw_hip.so")
-SOURCES = ["capi.cpp", "brain.hip", "dqn.hip", "assess_front.hip", "conv.hip", "bottleneck.hip", "bottleneck_wide.hip", "res2_stage.hip", "stem.hip", "assess.hip", "metrics.hip", "seg_epilogue.hip", "p2p.hip"]  # missing files are skipped
+SOURCES = ["capi.cpp", "brain.hip", "dqn.hip", "assess_front.hip", "conv.hip", "bottleneck.hip", "bottleneck_wide.hip", "res2_stage.hip", "stage_first.hip", "stem.hip", "assess.hip", "metrics.hip", "seg_epilogue.hip", "p2p.hip"]  # missing files are skipped
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("IVOSW_ABLATION") == "1":      # tuning builds only: compiles the ablation switches in (common.h)
     FLAGS.append("-DIVOSW_ABLATION=1")

@@ -83,8 +83,10 @@ static Plan make_plan(int dtype) {
                     bp.f1_off = take((size_t)planes[s] * inpl * es);
                     bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
                 }
-                if (dtype == IVOSW_BF16 && s == 1)       // res3's first 1x1 runs inside res2's last block (conv1 forwarding)
+                if (dtype == IVOSW_BF16 && s == 1) {     // res3's first 1x1 runs inside res2's last block (conv1 forwarding)
                     bp.fwd1_off = take((size_t)planes[s] * inpl * es);
+                    bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);    // ... and the rest of the block in stage_first_kernel
+                }
             } else if (dtype == IVOSW_BF16) {
                 bp.f1_off = take((size_t)planes[s] * inpl * es);
                 bp.f2_off = take((size_t)planes[s] * 9 * planes[s] * es);
@@ -206,7 +208,10 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
             if (bp.f3_off) launch_fragpack(base + c3.w_off, c3.Cout, c3.Cin, base + bp.f3_off, st);
         }
     for (const BlockPlan& bp : P.blocks)
-        if (bp.fwd1_off) launch_fragpack(base + P.convs[bp.c1].w_off, P.convs[bp.c1].Cout, P.convs[bp.c1].Cin, base + bp.fwd1_off, st);
+        if (bp.fwd1_off) {
+            launch_fragpack(base + P.convs[bp.c1].w_off, P.convs[bp.c1].Cout, P.convs[bp.c1].Cin, base + bp.fwd1_off, st);
+            if (bp.f2_off && !bp.f1_off) launch_fragpack(base + P.convs[bp.c2].w_off, P.convs[bp.c2].Cout, 9 * P.convs[bp.c2].Cin, base + bp.f2_off, st);
+        }
     for (const BlockPlan& bp : P.blocks)
         if (bp.ds >= 0) {
             const ConvPlan &c3 = P.convs[bp.c3], &cd = P.convs[bp.ds];
@@ -250,7 +255,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 extern "C" int ivosw_assess_split(int dtype, int B, int chunk) { return split_wanted(dtype, B, chunk, 0) ? 1 : 0; }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
-    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
+    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|stage_first*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
 static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,
@@ -518,6 +523,23 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 if (bneck_fusable(q)) {
                     launch_bneck(q, st);
                     x = y;
+                    continue;
+                }
+            }
+            if (dtype == IVOSW_BF16 && s == 1 && b == 0 && fwd2 && bp.ds >= 0 && bp.f2_off && bp.cat_fw_off && tune_get("FIRST3", 1)) {
+                // res3's first block behind its forwarded conv1 as ONE launch: t2 never leaves LDS (stage_first.hip; bit-identical to the
+                // two layer launches below)
+                StageFirstArgs q{};
+                q.t1 = bf.m1; q.x2 = x; q.y = y; q.zeros = base + P.zero_off;
+                q.fw2 = base + bp.f2_off; q.b2 = reinterpret_cast<const float*>(base + c2.b_off);
+                q.fwc = base + bp.cat_fw_off; q.bc = reinterpret_cast<const float*>(base + bp.cat_b_off);
+                q.B = nb; q.Ho = ho; q.Wo = ho; q.Cm = c2.Cout; q.C2 = P.convs[bp.ds].Cin;
+                q.H2 = ys2 ? hw / 2 : hw; q.W2 = q.H2; q.stride2 = ys2 ? 1 : 2;
+                if (stage_first_ok(q)) {
+                    q.rev = next_dir();
+                    launch_stage_first(q, st);
+                    x = y;
+                    hw = ho;
                     continue;
                 }
             }

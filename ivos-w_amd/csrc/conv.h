@@ -24,6 +24,22 @@ struct ConvArgs {
 
 void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st);
 
+// res3's first bottleneck behind its conv1 (3x3 stride 2, then [conv3 | downsample]) as one launch, bf16 (stage_first.hip)
+struct StageFirstArgs {
+    const void* t1;      // NHWC [B, 2 Ho, 2 Wo, Cm]: conv1's output (res2's last block forwards it)
+    const void* x2;      // NHWC [B, H2, W2, C2]: the block input, sampled at (oy * stride2, ox * stride2) for the downsample
+    void* y;             // NHWC [B, Ho, Wo, 4 Cm]
+    const void* fw2;     // 3x3 weights [Cm][9 Cm] in MFMA-operand order (launch_fragpack)
+    const float* b2;     // [Cm]
+    const void* fwc;     // [conv3 | downsample] weights [4 Cm][Cm + C2] in MFMA-operand order
+    const float* bc;     // [4 Cm]: the two folded BN shifts summed
+    const void* zeros;   // >= 256 B of device zeros
+    int B, Ho, Wo, Cm, C2, H2, W2, stride2;
+    int nt, rev;
+};
+bool stage_first_ok(const StageFirstArgs& a);
+void launch_stage_first(const StageFirstArgs& a, hipStream_t st);
+
 // one whole identity bottleneck (1x1 -> 3x3 -> 1x1 + residual), bf16, fused in one kernel (bottleneck.hip)
 struct BneckArgs {
     const void* x;       // NHWC [B,H,W,Cin]; also the residual

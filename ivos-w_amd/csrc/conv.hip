@@ -1223,9 +1223,12 @@ extern "C" int ivosw_profile_report(char* buf, size_t cap) {
         const double cm = a.Cout / 4.0;
         // K = -2: the whole of res2 + res3's forwarded conv1 in one launch (res2_stage.hip): 1 006 632 960 algorithmic MACs per frame
         // (b0 301 989 888, b1 / b2 285 212 672 each, forwarded 1x1 134 217 728); bytes = pooled stem output in, even-pixel y2 + t1' out
+        // K = -3: res3's first block behind its conv1 in one launch (stage_first.hip): 3x3 stride 2 + [conv3 | downsample]
         const double flops = a.KH == -2 ? 2.0 * a.B * 1006632960.0
+                           : a.KH == -3 ? 2.0 * M * (9.0 * a.Cin * a.Cin + (double)a.Cout * (a.Cin + a.Cin2))
                            : a.KH ? 2.0 * M * a.Cout * (a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0)) : 2.0 * M * (a.Cin * cm + 9.0 * cm * cm + cm * a.Cout);
         const double bytes = a.KH == -2 ? (double)a.B * (64.0 * 64 * 64 + 32.0 * 32 * 256 + 64.0 * 64 * 128) * r.es
+                           : a.KH == -3 ? ((double)a.B * a.H * a.W * a.Cin + M * (a.Cin2 + a.Cout)) * r.es
                            : a.KH ? ((double)a.B * a.H * a.W * a.Cin + M * a.Cout * (a.res ? 2 : 1) + (double)a.Cout * a.KH * a.KW * a.Cin) * r.es
                                   : (M * (a.Cin + a.Cout) + a.Cin * cm + 13.0 * cm * cm) * r.es;
         const double t = r.ms / r.n * 1e-3;

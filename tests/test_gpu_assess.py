@@ -188,6 +188,29 @@ def test_wide_fused_bottleneck_matches_layerwise(dev, net16):
             np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
 
 
+def test_fused_first_block_of_res3_is_bit_identical_to_the_two_layer_launches(dev, net16):
+    """stage_first_kernel (tunable FIRST3=1, default): res3's first bottleneck behind its forwarded conv1 — 3x3 stride 2, then
+    [conv3 | downsample] — as ONE launch with t2 in LDS, against conv_igemm_ws_kernel + conv1x1_wide_kernel.  Same operands, same
+    K order, same roundings: the res3 / res4 taps (block input sampled from the full-resolution y2: stride-2 addressing) and the
+    scores (y2 written at the even pixels only: the compact source) are identical BIT FOR BIT, on border-touching boxes and
+    on odd / chunk-crossing batches."""
+    from ivos_w_amd import _lib as L
+    for B, edge in ((8, True), (3, False), (21, True)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        got = {}
+        try:
+            for mode in (1, 0):
+                L.tune_set(b"FIRST3", mode)
+                taps = [net16.forward_tap(ttf, ttp, nm)[1].float().cpu().numpy() for nm in ("res3", "res4")]
+                got[mode] = (taps, net16(ttf, ttp).cpu().numpy())
+        finally:
+            L.tune_set(b"FIRST3", 1)
+        for a, b in zip(got[1][0], got[0][0]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(got[1][1], got[0][1])
+        assert np.isfinite(got[1][1]).all() and np.abs(got[1][0][0]).max() > 0
+
+
 def test_wide_1x1_conv_matches_tiled_kernel(dev, net16):
     """bf16 mode: the K-heavy 1x1 layers (first-block reductions, conv3 + folded downsample, res5) through
     conv1x1_wide_kernel (fragment-ordered wave-private weights, tunable WIDE1X1=1, default) against the LDS-tiled
