@@ -771,7 +771,7 @@ def bench_recommend(rank, dev, n=100, O=3, reps=8):
         ms = e0.elapsed_time(e1) / reps_e
         units = nf * no
         eval_sizes[f"{nf}x{no}"] = {"units": units, "ms": round(ms, 3), "units_per_s": round(units / ms * 1e3, 1),
-                                    "frac": round(units * GFLOP_PER_FRAME / ms / 1e6 / PEAK_BF16_TFLOPS, 4)}
+                                    "frac": round(units * GFLOP_PER_FRAME / ms / PEAK_BF16_TFLOPS, 4)}
     return {"metric": "recommend_frame_latency_ms", "frames": n, "objects": O, "first_call_ms": round(t_first * 1e3, 2),
             "eval_sizes": eval_sizes,
             "value": round(t_next * 1e3, 2), "unit": "ms per interaction (video cached on the device)",
