@@ -48,11 +48,12 @@ static void run(unsigned char* y, int cout, int tiles, int ncu) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double)iters * tiles * 256.0 * cout * 2;
-    printf("Cout %5d  seg %4d B  %s  %7.1f us  %7.1f GB/s\n", cout, SEG, NT ? "nt   " : "plain", ms * 1e3 / iters, bytes / ms / 1e6);
+    printf("CUs %3d  Cout %5d  seg %4d B  %s  %7.1f us  %7.1f GB/s  %5.1f GB/s per CU\n", ncu, cout, SEG, NT ? "nt   " : "plain", ms * 1e3 / iters, bytes / ms / 1e6,
+           bytes / ms / 1e6 / ncu);
 }
 
-int main() {
-    int ncu = 256;
+int main(int argc, char** argv) {
+    int ncu = argc > 1 ? atoi(argv[1]) : 256;        // workgroups (= CUs storing at once): 256, or fewer to see the per-CU rate alone
     const size_t total = (size_t)256 << 20;          // 256 MB written per pass: the size of a res3 / res4 activation tensor at B = 256
     unsigned char* y;
     hipMalloc(&y, total);
