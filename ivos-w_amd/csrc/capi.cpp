@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -35,24 +37,34 @@ DeviceScope::~DeviceScope() {
 }  // namespace ivosw
 
 namespace ivosw {
-// Tunables: fixed table, looked up by name.  Not thread-safe against concurrent ivosw_tune_set (tuning/test hook).
+// Tunables: fixed table, looked up by name.  Lookups and first-use insertion are safe from several host threads; two threads SETTING the same key
+// race on its value like any unsynchronised int (tuning / test hook).
 // The sources read 47 distinct keys (grep tune_get); the table holds every one of them set at once plus a cache entry per key
 // for the environment default (IVOSW_TUNE_<KEY> is read ONCE per key and process: a forward pass asks for ~40 keys).
 struct Tunable { char key[32]; int value; bool set, env_read, env_has; };
 constexpr int kMaxTunables = 160;
 static_assert(kMaxTunables >= 3 * 47, "the tunables table must hold every key the sources read, with room to grow");
 static Tunable g_tun[kMaxTunables];
-static int g_ntun = 0;
+static std::atomic<int> g_ntun{0};
+static std::mutex g_tun_mu;
 
+// Entries are append-only: lookups scan without a lock (the count is read with acquire, an entry is complete before it is published);
+// appending — a key's first tune_get / tune_set, from whichever host thread — takes the mutex and re-checks.
 static Tunable* tune_find(const char* key, bool create) {
-    for (int i = 0; i < g_ntun; ++i)
+    int n = g_ntun.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
         if (strcmp(g_tun[i].key, key) == 0) return &g_tun[i];
-    if (!create || g_ntun >= kMaxTunables || strlen(key) >= sizeof(g_tun[0].key)) return nullptr;
-    Tunable* t = &g_tun[g_ntun];
+    if (!create || strlen(key) >= sizeof(g_tun[0].key)) return nullptr;
+    std::lock_guard<std::mutex> lock(g_tun_mu);
+    const int m = g_ntun.load(std::memory_order_acquire);
+    for (int i = n; i < m; ++i)
+        if (strcmp(g_tun[i].key, key) == 0) return &g_tun[i];
+    if (m >= kMaxTunables) return nullptr;
+    Tunable* t = &g_tun[m];
     strcpy(t->key, key);
     t->value = 0;
     t->set = t->env_read = t->env_has = false;
-    ++g_ntun;                                        // published last: a concurrent reader sees a complete entry or none
+    g_ntun.store(m + 1, std::memory_order_release);
     return t;
 }
 
