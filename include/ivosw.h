@@ -36,6 +36,10 @@ extern "C" {
 
 #define IVOSW_F32 0             /* fp32 operands, fp32 accumulate (parity mode)                */
 #define IVOSW_BF16 1            /* bf16 operands, fp32 accumulate (throughput mode)            */
+#define IVOSW_F32X3 2           /* fp32 activations and weights, contractions as THREE bf16 MFMA passes: x = hi + lo with hi, lo in bf16,
+                                 * a b ~ ah bh + ah bl + al bh, fp32 accumulate (error ~ 2^-17 per product: scores within 1e-4 rtol of the
+                                 * reference like IVOSW_F32, at 16 / 3 of its matrix rate).  Layout and workspaces are IVOSW_F32's;
+                                 * the packed arena holds the conv weights pre-split, so it must be packed with this dtype.            */
 
 /* Brain parameter arena: the 10 tensors of Brain.state_dict() concatenated in state_dict order
  * (models/agent.py:13-31): encoder_fc1.{weight[128,2],bias[128]}, encoder_fc2.{weight[128,128],bias[128]},

@@ -171,14 +171,14 @@ static size_t carve(Arena& ar, int dtype, int B, int c0, Bufs* out) {
 using namespace ivosw;
 
 extern "C" size_t ivosw_assess_packed_bytes(int dtype) {
-    if (dtype != IVOSW_F32 && dtype != IVOSW_BF16) return 0;
+    if (dtype != IVOSW_F32 && dtype != IVOSW_BF16 && dtype != IVOSW_F32X3) return 0;
     return plan_for(dtype).total;
 }
 
 extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* tensors, int ntensors, ivosw_stream_t stream) {
     IVOSW_REQUIRE(packed && tensors, "null pointer");
     IVOSW_ON_DEVICE_OF(packed);
-    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
+    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16 || dtype == IVOSW_F32X3, "dtype must be IVOSW_F32, IVOSW_BF16 or IVOSW_F32X3");
     IVOSW_REQUIRE(ntensors == IVOSW_ASSESS_NTENSORS, "expected the 326 tensors of AssessNet.state_dict()");
     const Plan& P = plan_for(dtype);
     IVOSW_REQUIRE(P.t_fcb == IVOSW_ASSESS_NTENSORS - 1, "internal: plan/state_dict mismatch");
@@ -220,6 +220,14 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
                             reinterpret_cast<float*>(base + bp.cat_b_off), st);
             if (bp.cat_fw_off) launch_fragpack(base + bp.cat_w_off, c3.Cout, c3.Cin + cd.Cin, base + bp.cat_fw_off, st);
         }
+    if (dtype == IVOSW_F32X3) {
+        // the three-pass mode reads pre-split weights (conv.hip: ktile_mma_x3): every conv's K-major array and the concatenated
+        // [conv3 | downsample] arrays, in place, AFTER everything that read them as fp32 (the concatenation above)
+        launch_split_weights_x3(base + P.stem_w_off, 64, 224, st);       // the stem: 7 filter rows x 8 pixels x 4 channels per output channel
+        for (const ConvPlan& c : P.convs) launch_split_weights_x3(base + c.w_off, c.Cout, c.K * c.K * c.Cin, st);
+        for (const BlockPlan& bp : P.blocks)
+            if (bp.ds >= 0) launch_split_weights_x3(base + bp.cat_w_off, P.convs[bp.c3].Cout, P.convs[bp.c3].Cin + P.convs[bp.ds].Cin, st);
+    }
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
@@ -247,7 +255,7 @@ static size_t ws_split(int dtype, int B) {
 }
 
 extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk) {
-    if ((dtype != IVOSW_F32 && dtype != IVOSW_BF16) || B <= 0 || H <= 0 || W <= 0) return 0;
+    if ((dtype != IVOSW_F32 && dtype != IVOSW_BF16 && dtype != IVOSW_F32X3) || B <= 0 || H <= 0 || W <= 0) return 0;
     const size_t one = ws_single(dtype, B, chunk);
     return split_wanted(dtype, B, chunk, 0) ? std::max(one, ws_split(dtype, B)) : one;
 }
@@ -321,7 +329,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
                                ivosw_stream_t stream) {
     IVOSW_REQUIRE(packed && tf && tp && scores && ws, "null pointer");
     IVOSW_ON_DEVICE_OF(scores);
-    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
+    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16 || dtype == IVOSW_F32X3, "dtype must be IVOSW_F32, IVOSW_BF16 or IVOSW_F32X3");
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
     IVOSW_REQUIRE((long)H * W <= INT_MAX, "frame too large (H * W <= INT_MAX)");
     IVOSW_REQUIRE(tap_stage >= 0 && tap_stage <= 8, "tap_stage out of range");

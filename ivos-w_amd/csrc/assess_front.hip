@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const float* __restrict
 
 void launch_roi_sample(const float* tf, const float* tp, const float* yxhw, int b0, int B, int H, int W, int dtype,
                        const SampleMap& sm, const RoiNorm& nrm, void* roi, hipStream_t st) {
-    if (dtype == IVOSW_F32)
+    if (dtype != IVOSW_BF16)
         hipLaunchKernelGGL(roi_sample_kernel<float>, dim3(B * (256 / ROI_R)), dim3(256), 0, st, tf, tp, yxhw, b0, sm, H, W, nrm,
                            static_cast<float*>(roi));
     else
@@ -261,7 +261,7 @@ extern "C" int ivosw_roi_sample(const float* tf, const float* tp, const float* y
     IVOSW_ON_DEVICE_OF(roi);
     IVOSW_REQUIRE(B > 0 && H > 1 && W > 1, "B must be positive and H, W > 1");
     IVOSW_REQUIRE((long)H * W <= INT_MAX && B <= (1 << 24), "frame or batch too large (H * W <= INT_MAX, B <= 2^24)");
-    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16, "dtype must be IVOSW_F32 or IVOSW_BF16");
+    IVOSW_REQUIRE(dtype == IVOSW_F32 || dtype == IVOSW_BF16 || dtype == IVOSW_F32X3, "dtype must be IVOSW_F32, IVOSW_BF16 or IVOSW_F32X3");
     RoiNorm nrm{{0.485f, 0.456f, 0.406f}, {0.229f, 0.224f, 0.225f}, nullptr};  // Encoder.mean/std (assessment.py:41-44)
     launch_roi_sample(tf, tp, yxhw, 0, B, H, W, dtype, SampleMap{B, (long)H * W, 0}, nrm, roi, as_stream(stream));
     IVOSW_CHECK_LAUNCH();

@@ -91,9 +91,60 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
     }
 }
 
+// ---------------------------------------------------------------- split-bf16 contraction of one fp32 K-tile (IVOSW_F32X3)
+// A K-tile is 32 fp32 activations per row (128 B) and, for the weights, the same 32 k as [32 x bf16 hi | 32 x bf16 lo] (128 B, split
+// at pack time: launch_split_weights_x3).  Two 32x32x16 MFMA steps per K-tile; in step s lane half h supplies k = 16 s + 8 h + [0, 8):
+// activations from 16-byte chunks 4 s + 2 h and 4 s + 2 h + 1 (eight floats, split here: hi = truncation — one v_perm per pair —,
+// lo = RNE(x - hi), exact difference), weights from chunk 2 s + h (hi) and 4 + 2 s + h (lo).  Three products per operand pair:
+// ah bh + ah bl + al bh; the dropped al bl is ~ 2^-17 of the product, like the rounding of the lo parts.
+__device__ __forceinline__ void split8_x3(const u32x4& c0, const u32x4& c1, u32x4& hi, u32x4& lo) {
+    const unsigned x[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hi[q] = __builtin_amdgcn_perm(x[2 * q + 1], x[2 * q], 0x07060302u);      // high halves of x[2q+1] | x[2q]
+        const float l0 = __uint_as_float(x[2 * q]) - __uint_as_float(x[2 * q] & 0xffff0000u);
+        const float l1 = __uint_as_float(x[2 * q + 1]) - __uint_as_float(x[2 * q + 1] & 0xffff0000u);
+        lo[q] = pack2_bf16(l0, l1);
+    }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void ktile_mma_x3(f32x16 (&acc)[TM][TN], unsigned a_base, unsigned b_base, int wm, int wn, int lrow, int lhalf) {
+    u32x4 a0[2][TM], a1[2][TM], bh[2][TN], bl[2][TN];
+    auto frag_read = [&](int s, int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            a0[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, 4 * s + 2 * lhalf));
+            a1[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, 4 * s + 2 * lhalf + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[buf][j] = lds_read_b128(b_base + swz((wn * TN + j) * 32 + lrow, 2 * s + lhalf));
+            bl[buf][j] = lds_read_b128(b_base + swz((wn * TN + j) * 32 + lrow, 4 + 2 * s + lhalf));
+        }
+    };
+    frag_read(0, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        lds_wait();
+        if (s < 1) frag_read(1, 1);
+        u32x4 ah[TM], al[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) split8_x3(a0[s][i], a1[s][i], ah[i], al[i]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = mfma_bf16(ah[i], bh[s][j], acc[i][j]);
+                acc[i][j] = mfma_bf16(ah[i], bl[s][j], acc[i][j]);
+                acc[i][j] = mfma_bf16(al[i], bh[s][j], acc[i][j]);
+            }
+    }
+}
+
 // WAVES_M x WAVES_N waves (4 total), each owning TM x TN 32x32 MFMA tiles.
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, bool STEM>
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, bool STEM, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    static_assert(!X3 || sizeof(T) == 4, "the three-pass split is a mode of the fp32 tensors");
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int ES = (int)sizeof(T);
     constexpr int KE = ROWB / ES;   // elements per K-tile (64 bf16 / 32 fp32)
@@ -203,6 +254,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         if (kt + 1 < nk) load_tiles(kt + 1);
         const unsigned char* As = lds + buf * STAGE_BYTES;
         const unsigned char* Bs = As + BM * ROWB;
+        if constexpr (X3) {
+            const unsigned lb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + buf * STAGE_BYTES;
+            ktile_mma_x3<TM, TN>(acc, lb, lb + BM * ROWB, wm, wn, lrow, lhalf);
+        } else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             // 16-B chunk (2*ks + lhalf): bf16 -> k = 16*ks + 8*lhalf + [0,8) (one 32x32x16 MFMA);
@@ -256,8 +311,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 // lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied on the SOURCE side: the lane that
 // lands on chunk position p of row r fetches chunk p ^ ((r>>1)&7); reads use the same involution.  Zero padding:
 // out-of-image taps fetch from a 16-B page of zeros.
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S>
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S, bool X3 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(ConvArgs p) {
+    static_assert(!X3 || sizeof(T) == 4, "the three-pass split is a mode of the fp32 tensors");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int ES = (int)sizeof(T);
@@ -381,6 +437,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
         asm volatile("" ::: "memory");
         if (kt + S - 1 < nk && !ABL(p.debug, 4)) issue(kt + S - 1, fill);   // refill the slot tile kt-1 just vacated
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
+        if constexpr (X3) {
+            ktile_mma_x3<TM, TN>(acc, a_base, b_base, wm, wn, lrow, lhalf);
+            stage = (stage + 1 == S) ? 0 : stage + 1;
+            fill = (fill + 1 == S) ? 0 : fill + 1;
+            continue;
+        }
         u32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int ks, int buf) {
             const int ch = 2 * ks + lhalf;
@@ -437,8 +499,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
 // Same ring / swizzle / epilogue, but LW extra waves (one per SIMD) do nothing except issue the LDS-DMA and count
 // it: an LDS-DMA wave-instruction occupies its wave's issue slot for ~60-180 cycles, which the in-order compute
 // waves above pay in front of their MFMAs.  Here the NW compute waves only run {barrier, ds_read, MFMA}.
-template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S, int LW>
+template <typename T, int WAVES_M, int WAVES_N, int TM, int TN, int S, int LW, bool X3 = false>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_kernel(ConvArgs p) {
+    static_assert(!X3 || sizeof(T) == 4, "the three-pass split is a mode of the fp32 tensors");
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int ES = (int)sizeof(T);
@@ -569,6 +632,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
         asm volatile("" ::: "memory");
         if ABL(p.debug, 8) continue;                   // ablation: loaders + barriers only (pure fill rate of the real access pattern)
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
+        if constexpr (X3) {
+            ktile_mma_x3<TM, TN>(acc, a_base, b_base, wm, wn, lrow, lhalf);
+            stage = (stage + 1 == S) ? 0 : stage + 1;
+            continue;
+        }
         u32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int ks, int buf) {
             const int ch = 2 * ks + lhalf;
@@ -832,12 +900,12 @@ static bool patch3x3_ok(const ConvArgs& a) {
     return a.H == 32 || a.H == 16 || a.H == 8;
 }
 
-template <typename T, bool STEM>
+template <typename T, bool STEM, bool X3 = false>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
     const int M = a.B * a.Ho * a.Wo;
     if constexpr (STEM) {
         const int grid = ((M + 127) / 128) * (a.Cout / 64);
-        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 1, true>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 2, 1, true, X3>), dim3(grid), dim3(256), 0, st, a);
     } else {
         // Tile / ring selection.  8 waves (2 per SIMD) so one wave's LDS-DMA issue overlaps the other's MFMAs;
         // 256-row tiles halve the DMA instructions per MFMA.  Short K loops (1x1 convs on 64/128 channels) use a
@@ -860,23 +928,23 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
             // workgroups per CU - twice the workgroups; same K order per output element, so a frame's result does not depend on it
             if (nk > tune_nk && grid < tune_get("SMALL_GRID", 128)) {
                 const int g2 = ((M + 127) / 128) * (a.Cout / 128);
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 3>), dim3(g2), dim3(512), 0, st, a);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 3, X3>), dim3(g2), dim3(512), 0, st, a);
                 return;
             }
 
-            if (nk > tune_nk && use_ws && lw == 8) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 8>), dim3(grid), dim3(1024), 0, st, a);
-            else if (nk > tune_nk && use_ws) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 4>), dim3(grid), dim3(768), 0, st, a);
-            else if (nk > tune_nk) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3>), dim3(grid), dim3(512), 0, st, a);
+            if (nk > tune_nk && use_ws && lw == 8) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 8, X3>), dim3(grid), dim3(1024), 0, st, a);
+            else if (nk > tune_nk && use_ws) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 2, 3, 4, X3>), dim3(grid), dim3(768), 0, st, a);
+            else if (nk > tune_nk) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 2, 3, X3>), dim3(grid), dim3(512), 0, st, a);
             else {  // K <= 128: bound by the output/residual stream -> 128x128 tiles, 64 KB LDS, 2 workgroups per CU
                 const int g2 = ((M + 127) / 128) * (a.Cout / 128);
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 2>), dim3(g2), dim3(512), 0, st, a);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 2, X3>), dim3(g2), dim3(512), 0, st, a);
             }
         } else {  // Cout == 64 layers: 256 x 64 tile
             const int grid = ((M + 255) / 256) * (a.Cout / 64);
             static const int use_ws64 = getenv("IVOSW_TUNE_WS") ? atoi(getenv("IVOSW_TUNE_WS")) : 1;
-            if (nk >= 4 && use_ws64) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 1, 3, 4>), dim3(grid), dim3(768), 0, st, a);
-            else if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 3>), dim3(grid), dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 2>), dim3(grid), dim3(512), 0, st, a);
+            if (nk >= 4 && use_ws64) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 1, 3, 4, X3>), dim3(grid), dim3(768), 0, st, a);
+            else if (nk >= 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 3, X3>), dim3(grid), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 2, 1, 2, X3>), dim3(grid), dim3(512), 0, st, a);
         }
     }
 }
@@ -958,13 +1026,45 @@ void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
         a.nmajor = (nm == 1) || (nm == 2 && a.KH == 3);
         a.nt = tune_get("NT", 3);   // streaming tensors are far larger than L2: keep them from evicting the A / weight lines that ARE reused
     }
+    a.x3 = dtype == IVOSW_F32X3 ? 1 : 0;
     void* tok = prof_begin(a, (dtype == IVOSW_BF16) ? 2 : 4, st);
     if (dtype == IVOSW_BF16) {
         if (stem) launch_conv_t<bf16_t, true>(a, st); else launch_conv_t<bf16_t, false>(a, st);
+    } else if (a.x3) {
+        if (stem) launch_conv_t<float, true, true>(a, st); else launch_conv_t<float, false, true>(a, st);
     } else {
         if (stem) launch_conv_t<float, true>(a, st); else launch_conv_t<float, false>(a, st);
     }
     prof_end(tok, st);
+}
+
+// [rows][K] fp32, in place: K-tile t of a row (floats 32 t .. 32 t + 31, 128 bytes) -> 32 x bf16 hi | 32 x bf16 lo
+__global__ void split_weights_x3_kernel(float* __restrict__ w, long ntiles) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    float* base = w + t * 32;
+    float x[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(base)[q];
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+    uint32_t hi[16], lo[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        hi[q] = pack2_bf16(x[2 * q], x[2 * q + 1]);
+        const float h0 = __uint_as_float(hi[q] << 16), h1 = __uint_as_float(hi[q] & 0xffff0000u);
+        lo[q] = pack2_bf16(x[2 * q] - h0, x[2 * q + 1] - h1);
+    }
+    uint4* o = reinterpret_cast<uint4*>(base);       // every input of the tile has been read: in place is safe
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = make_uint4(hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[4 + q] = make_uint4(lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]);
+}
+void launch_split_weights_x3(void* w, long rows, int K, hipStream_t st) {
+    const long ntiles = rows * (K / 32);
+    hipLaunchKernelGGL(split_weights_x3_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, st, static_cast<float*>(w), ntiles);
 }
 
 // ---------------------------------------------------------------- weight packing (BN fold + K-major repack)

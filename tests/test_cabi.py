@@ -43,6 +43,8 @@ def test_host_only_queries(handle):
     nb16, nb32 = lib.ivosw_assess_packed_bytes(L.BF16), lib.ivosw_assess_packed_bytes(L.F32)
     assert 94e6 < nb32 < 130e6 and 47e6 < nb16 < 150e6
     assert lib.ivosw_assess_packed_bytes(7) == 0
+    assert lib.ivosw_assess_packed_bytes(L.F32X3) == nb32      # the three-pass mode keeps the fp32 layout (weights pre-split in place)
+    assert lib.ivosw_assess_ws_bytes(L.F32X3, 64, 480, 854, 0) == lib.ivosw_assess_ws_bytes(L.F32, 64, 480, 854, 0)
     assert lib.ivosw_assess_ws_bytes(L.BF16, 256, 480, 854, 0) > 0
     fam = lib.ivosw_assess_dominant_kernel(L.BF16).decode().split("|")
     assert "conv_igemm*" in fam and "bneck*" in fam           # kernel-name patterns of the tower's contraction kernels

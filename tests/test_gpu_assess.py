@@ -113,6 +113,42 @@ def test_spread_weights_vs_reference_golden(dev, gold):
     print(f"spread fixture: fp32 worst rel {np.max(np.abs(s32 - ref) / np.abs(ref)):.2e}, bf16 worst rel {np.max(np.abs(s16 - ref) / np.abs(ref)):.2e}")
 
 
+def test_bf16x3_mode_meets_the_fp32_bars_against_the_reference_goldens(dev, gold, net32):
+    """precision='bf16x3' (IVOSW_F32X3: fp32 tensors, every contraction — the stem included — as three bf16 MFMA passes on (hi, lo)
+    splits: a b ~ ah bh + ah bl + al bh, the weights split at pack time) is held to the FP32 mode's bars on the fixtures recorded from
+    the reference: every tap slice / per-sample checksum at the fp32 tolerances, scores within 1e-4 rtol (north_star) for B = 8 (edge
+    masks), 1, 3 (ragged chunks) and the spread-weight fixture (frame-to-frame differences and ranking too), and within 2e-5 of the
+    exact-fp32 mode frame by frame; a frame's score does not depend on the batch it travels in (chunked = unchunked, bit for bit)."""
+    nx = make_net(dev, "bf16x3")
+    worst = 0.0
+    for tag, B, edge in (("B8", 8, True), ("B1", 1, False), ("B3", 3, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        if tag != "B3":
+            for nm in ("stem", "pool", "res2", "res3", "res4", "res5"):
+                _, t = nx.forward_tap(ttf, ttp, nm)
+                assert t.dtype == torch.float32
+                a = t.cpu().numpy().transpose(0, 3, 1, 2)
+                np.testing.assert_allclose(_slice4(a), gold[f"slice_{tag}_{nm}"], rtol=1e-3, atol=3e-4, err_msg=nm)
+                np.testing.assert_allclose(_stat(a), gold[f"stat_{tag}_{nm}"], rtol=2e-5, err_msg=nm)
+        got = nx(ttf, ttp).cpu().numpy()
+        ref = gold[f"{tag}_score"]
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=1e-4)
+        np.testing.assert_allclose(got, net32(ttf, ttp).cpu().numpy(), rtol=2e-5)
+        worst = max(worst, float(np.max(np.abs(got - ref) / np.abs(ref))))
+    _, _, ttf, ttp = inputs(dev, 8, True)
+    a = nx(ttf, ttp).cpu().numpy()
+    for chunk in (3, 2):
+        np.testing.assert_array_equal(make_net(dev, "bf16x3", chunk=chunk)(ttf, ttp).cpu().numpy(), a)
+    ns = make_net(dev, "bf16x3", spread=True)
+    ref = gold["S8_score"]
+    s = ns(ttf, ttp).cpu().numpy()
+    np.testing.assert_allclose(s, ref, rtol=1e-4)
+    np.testing.assert_allclose(s - s.mean(), ref - ref.mean(), atol=1e-4 * np.abs(ref).max())
+    assert np.array_equal(np.argsort(s.ravel()), np.argsort(ref.ravel()))
+    print(f"bf16x3 worst relative score error vs reference: {max(worst, float(np.max(np.abs(s - ref) / np.abs(ref)))):.2e}")
+
+
 def test_fp32_b3_and_chunking(dev, gold):
     _, _, ttf, ttp = inputs(dev, 3, False)
     net = make_net(dev, "fp32", chunk=2)                  # ragged last chunk
