@@ -55,7 +55,7 @@ DEFAULTS = dict(
     seed=0, gpu_id=0, phase="eval", setting="wild", method="ours", num_epochs=1, dataset="davis", ckpt_dir="weights",
     vos_adapter="",                    # module on PYTHONPATH that wraps the VOS backbone for the real stack (default ivosw_vos_<backbone>)
     synthetic=-1,                      # -1 auto (synthetic when the real stack is missing), 0 real stack only, 1 synthetic
-    precision="bf16",                  # AssessNet mode: bf16 throughput / fp32 parity
+    precision="bf16",                  # AssessNet mode: bf16 throughput (scores within 4e-3) / bf16x3 fast parity (1e-4) / fp32 exact parity
     report_save_dir="results",
     eval_max_nb_interactions=8,        # the eval scripts fix 8 interactions on the val subset (eval_agent_manet.py:64-65)
     data=dict(num_workers=0, root_dir_davis="data/DAVIS", root_dir_scribble_youtube_vos="data/Scribble_Youtube_VOS",
