@@ -77,8 +77,13 @@ def dist_setup(n):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or FORCE_DIST[0]:
         import torch.distributed as dist_
+        if world == 1:                       # --force-dist: a process group of one rank, through the same backend
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if BACKEND[0] == "nccl":
             dist_.init_process_group("nccl", device_id=dev)
         else:
@@ -88,6 +93,7 @@ def dist_setup(n):
 
 
 BACKEND = ["nccl"]
+FORCE_DIST = [False]     # --force-dist: N = 1 through the N > 1 branch (process group of one rank, the collective in every DQN step)
 
 
 def _free_port():
@@ -459,7 +465,7 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     agent, replay, gen = build_dqn(args, rank, dev)
     B = args.minibatch
     from ivos_w_amd import parallel
-    dp = world > 1 or args.dqn_dp_emulate          # the data-parallel step structure (gradients -> collective -> clamp + Adam)
+    dp = world > 1 or args.dqn_dp_emulate or FORCE_DIST[0]     # the data-parallel step structure (gradients -> collective -> clamp + Adam)
     fused = not dp
     seed = 2019 + 7919 * rank
     lean = None
@@ -478,7 +484,7 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     # peer-to-peer all-reduce fused with clamp + Adam (two launches), opt-in in the product (IVOSW_P2P=1) because its cross-GPU path
     # has never run outside this benchmark: it is attempted here (collective self-test against the backend's result) when
     # IVOSW_BENCH_P2P=1, and timed only if every rank passed.  dqn.value is the faster VALIDATED path; the timed paths are in dqn.collectives.
-    legs = [None]
+    legs = ["backend"] if FORCE_DIST[0] else [None]
     if world > 1:
         # the P2P leg is opt-in (IVOSW_BENCH_P2P=1): its cross-GPU path (IPC-mapped peer arenas, system-scope flags) has only ever run
         # between two processes on ONE device, and a fault there would take the whole N > 1 record down with it
@@ -580,10 +586,10 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     per_gpu_tflops = DQN_GFLOP_PER_STEP * 1e9 * (sps / world) / 1e12
     info = {"us_per_step": round(dt / steps * 1e6, 1), "graph": (cap is not None) if launch_mode is None else launch_mode["mode"] == "graph",
             "launch_mode": launch_mode,
-            "step_structure": "data-parallel: gradients -> collective -> clamp + Adam" + (" (emulated at N = 1, no collective)" if world == 1 else "") if dp else "single GPU: fused step",
+            "step_structure": "data-parallel: gradients -> collective -> clamp + Adam" + (" (emulated at N = 1, no collective)" if world == 1 and not FORCE_DIST[0] else " (forced at N = 1: the collective runs over one rank)" if world == 1 else "") if dp else "single GPU: fused step",
             "collective_path": (("one-shot xGMI peer-to-peer all-reduce fused with clamp + Adam (ivosw_p2p_allreduce_clamp_adam, self-tested against the backend's result at start-up)" if p2p is not None
-                                 else "RCCL all-reduce" if BACKEND[0] == "nccl" else "gloo all-reduce staged through host memory") if world > 1 else None),
-            "collectives": (leg_us if world > 1 and launch_mode is None else None),
+                                 else "RCCL all-reduce" if BACKEND[0] == "nccl" else "gloo all-reduce staged through host memory") if world > 1 or FORCE_DIST[0] else None),
+            "collectives": (leg_us if (world > 1 or FORCE_DIST[0]) and launch_mode is None else None),
             "kernel_nodes_in_graph": cap.kernel_nodes if cap is not None else None,
             "host_launches_per_step": (round(launches_per_step, 3) if launch_mode is not None else (1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
             "steps_per_graph_launch": args.dqn_block if loop is not None else (1 if cap is not None else None),
@@ -856,6 +862,8 @@ def main():
     ap.add_argument("--dqn-dp-emulate", action="store_true", help="N = 1: run the data-parallel step structure (no collective) to time it")
     ap.add_argument("--dqn-block", type=int, default=8, help="N = 1: training steps per hipGraphLaunch when no target-sync coin of the block fires (1 = one graph launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1 through the N > 1 branch: a process group of one rank on the chosen backend, barrier + "
+                    "max over ranks around the timed region, the gradient all-reduce in every DQN step (RCCL on a one-GPU box)")
     ap.add_argument("--layer-report", default="", help="write a per-conv-layer timing table (HIP events) to this file")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the 15 extra forward passes that measure roofline.sclk_mhz / power_w (profiling runs count passes)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not re-run the forward under rocprofv3 --pmc for roofline.traffic (the committed PMC summary is quoted instead)")
@@ -870,6 +878,11 @@ def main():
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:])
     BACKEND[0] = args.backend
+    if args.force_dist:
+        if args.gpus != 1:
+            raise SystemExit("--force-dist is the N = 1 run through the N > 1 branch")
+        FORCE_DIST[0] = True
+        os.environ["IVOSW_FORCE_DIST"] = "1"            # parallel.data_parallel_step: the collective runs over the one rank
     rank, world, dev, dist = dist_setup(args.gpus)
     args.total_batch = args.batch * world
     if args.scaling == "strong" and world > 1:
@@ -892,6 +905,8 @@ def main():
         return
     line = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "data": "synthetic"}
+    if FORCE_DIST[0]:
+        line["force_dist"] = f"process group of one rank on {BACKEND[0]}: barrier + max over ranks around every timed region, all-reduce in every DQN step"
     if args.workload == "assess":
         fps, dt, roof, extra = bench_assess(args, rank, world, dev, dist)
         if rank == 0 and world == 1 and not args.no_live_traffic and args.batch == 256 and args.precision == "bf16" and not args.chunk:
@@ -908,7 +923,7 @@ def main():
                      "dqn": dict({"metric": "dqn_agent_steps_per_sec", "value": round(dqn_sps, 1), "unit": "minibatch-steps/s (all ranks)",
                                   "transitions_per_sec": round(dqn_sps * args.minibatch, 1), "minibatch_per_gpu": args.minibatch,
                                   "replay": args.replay, "T": 25, "steps": args.dqn_steps,
-                                  "dtype": "f32", "collective": (dqn_info.get("collective_path") + " (724 KB)") if world > 1 else None}, **dqn_info)})
+                                  "dtype": "f32", "collective": (dqn_info.get("collective_path") + " (724 KB)") if world > 1 or FORCE_DIST[0] else None}, **dqn_info)})
         line.update(extra)
     else:
         sps, dt, info = bench_dqn(args, rank, world, dev, dist, args.steps, args.warmup)

@@ -239,8 +239,8 @@ class Agent(nn.Module):
         """clamp + Adam on policy_net.flat_grad; with torch.distributed initialised: synchronous data parallel — the gradients are
         summed over the ranks first (RCCL over xGMI, or the opt-in one-shot P2P all-reduce fused with the update) and averaged
         inside the kernel, so the clamp sees the averaged gradient as a single large batch would."""
-        _, world = self._world()
-        if world > 1:
+        dist, world = self._world()
+        if world > 1 or dist is not None:           # an initialised process group of one rank (IVOSW_FORCE_DIST=1) takes the same path
             from .. import parallel
             parallel.data_parallel_step(self.policy_net, self.optimizer, check_every)
         else:

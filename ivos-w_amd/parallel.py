@@ -15,6 +15,19 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """IVOSW_FORCE_DIST=1: a world of ONE rank still initialises the process group and sends its gradient arena through the
+    backend's all-reduce (the sum over one rank: bit-identical to the single-process step).  This is how the RCCL communicator,
+    the collective on the compute stream and the clamp + Adam behind it are exercised on a one-GPU box (tests/test_gpu_dist.py,
+    `bench.py --gpus 1 --force-dist`) instead of running for the first time on the 8-GPU node."""
+    return os.environ.get("IVOSW_FORCE_DIST", "0") == "1"
+
+
+def collective_active():
+    """True when the data-parallel step runs its collective: more than one rank, or a forced world of one."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+
+
 def init(backend=None):
     """Initialise from the torchrun environment (RANK/WORLD_SIZE/LOCAL_RANK/MASTER_*). Returns (rank, world, device)."""
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -24,10 +37,18 @@ def init(backend=None):
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         backend = backend or os.environ.get("IVOSW_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl" and use_gpu:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -261,13 +282,15 @@ def allreduce_grads(flat_grad, check_every=1):
             p2p.check(check_every)
         else:
             _backend_allreduce(flat_grad)
+    elif collective_active():
+        _backend_allreduce(flat_grad)         # forced world of one: the backend's all-reduce over a single rank
     return 1.0 / w
 
 
 def collective_path(flat_grad):
     """'p2p' | 'backend' | None (single process): which all-reduce the data-parallel step of this process uses."""
     if world() < 2:
-        return None
+        return "backend" if collective_active() else None
     return "p2p" if (flat_grad.is_cuda and p2p_for(flat_grad) is not None) else "backend"
 
 
@@ -277,7 +300,7 @@ def data_parallel_step(brain, optimizer, check_every=1):
     would).  P2P path: two launches (push | wait + sum + clamp + Adam); backend path: all-reduce, then the fused clamp + Adam."""
     w = world()
     if w < 2:
-        optimizer.grad_scale = 1.0
+        optimizer.grad_scale = allreduce_grads(brain.flat_grad, check_every) if collective_active() else 1.0
         optimizer.step()
         return
     grad = brain.flat_grad

@@ -107,3 +107,38 @@ def test_rank_batch_sampler_deals_the_shuffled_minibatches_out():
     other = RankBatchSampler(n, B, 1, world, 77)
     list(other)
     assert not set(sum(second, [])) & set(sum(list(other), []))
+
+
+def _forced_world1_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", IVOSW_FORCE_DIST="1")
+    r, w, dev = parallel.init("gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized() and parallel.collective_active() and parallel.forced()
+    g = torch.arange(1000, dtype=torch.float32) * 0.25 - 3.0
+    want = g.clone()
+    calls = []
+    real = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.data_ptr())
+        return real(t, *a, **k)
+    dist.all_reduce = counting
+    scale = parallel.allreduce_grads(g)
+    dist.all_reduce = real
+    assert scale == 1.0 and torch.equal(g, want) and calls == [g.data_ptr()]        # the sum over one rank, through the backend, in place
+    assert parallel.collective_path(g) == "backend"
+    dist.destroy_process_group()
+    os.environ["IVOSW_FORCE_DIST"] = "0"
+    assert not parallel.collective_active() and parallel.collective_path(g) is None
+    q.put("ok")
+
+
+def test_forced_world_of_one_goes_through_the_backend_collective():
+    """IVOSW_FORCE_DIST=1 (round 5): a single rank initialises the process group and its gradient arena takes the backend's all-reduce —
+    the host logic behind tests/test_gpu_dist.py::test_rccl_world1... and `bench.py --gpus 1 --force-dist`, here on gloo / CPU."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_world1_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=120) == "ok"
+    p.join(60)
+    assert p.exitcode == 0

@@ -294,3 +294,90 @@ def test_train_agent_data_parallel_under_torchrun(tmp_path):
     assert hist[-1]["updates"] > 0
     assert os.path.exists(os.path.join(work, "ckpt", "agent.pt"))
     assert os.path.isdir(os.path.join(work, "results", "rank1")) and not os.path.exists(os.path.join(work, "results", "rank1", "train_summary.json"))
+
+
+def _rccl_world1_worker(port, q):
+    """ONE rank, backend nccl (= RCCL): communicator creation, dist.all_reduce of the 724 KB gradient arena on the compute stream, the
+    fused clamp + Adam behind it — parallel.data_parallel_step exactly as a rank of the 8-GPU job runs it."""
+    import io
+    import contextlib
+    from ivos_w_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", IVOSW_FORCE_DIST="1",
+                      IVOSW_P2P="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r, w, dev = parallel.init("nccl")
+    assert dev.type == "cuda" and w == 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+    assert parallel.collective_active()
+    tr = synth.replay_transitions(n=2000, T=25, seed=2019)
+    agent = _agent(dev)
+    assert parallel.collective_path(agent.policy_net.flat_grad) == "backend"
+    calls = []
+    real = torch.distributed.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append((tuple(t.shape), t.device.type, t.data_ptr()))
+        return real(t, *a, **k)
+    torch.distributed.all_reduce = counting
+    np.random.seed(5)
+    out = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for s in range(STEPS):
+            agent.update_agent(_batch(tr, synth.minibatch_indices(s, n=2000, B=B, seed=7)))
+            out.append((agent.policy_net.flat_grad.cpu().numpy().copy(), agent.policy_net.flat.cpu().numpy().copy(),
+                        agent.target_net.flat.cpu().numpy().copy()))
+    torch.distributed.all_reduce = real
+    # every step sent the flat gradient arena itself (no staging copy) through the backend, on the device
+    assert len(calls) == STEPS and all(c == ((agent.policy_net.flat_grad.numel(),), "cuda", agent.policy_net.flat_grad.data_ptr()) for c in calls), calls
+    assert agent.optimizer.grad_scale == 1.0
+    q.put(out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_world1_three_steps_are_bit_identical_to_the_single_process_step():
+    """the RCCL path had never executed, not even at world size 1.  One rank initialises `nccl`, runs three
+    `update_agent` steps through parallel.data_parallel_step (all-reduce over the one rank, then clamp + Adam with scale 1) and must
+    reproduce the plain single-process steps BIT FOR BIT: gradients, parameters, Adam-driven target syncs."""
+    import io
+    import contextlib
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(port, q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    dev = torch.device("cuda:0")
+    tr = synth.replay_transitions(n=2000, T=25, seed=2019)
+    agent = _agent(dev)
+    np.random.seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        for s in range(STEPS):
+            agent.update_agent(_batch(tr, synth.minibatch_indices(s, n=2000, B=B, seed=7)))
+            for x, y in zip(got[s], (agent.policy_net.flat_grad, agent.policy_net.flat, agent.target_net.flat)):
+                np.testing.assert_array_equal(x, y.cpu().numpy())
+
+
+def test_bench_force_dist_runs_the_multi_rank_branch_on_rccl():
+    """`bench.py --gpus 1 --force-dist`: the N > 1 branch (process group, barrier + max over ranks around the timed regions, the
+    all-reduce inside every DQN step) on the nccl backend with one rank — what the driver's 2 / 4 / 8-GPU runs execute per rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("IVOSW_FORCE_DIST", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--batch", "32",
+                        "--min-warm-s", "0", "--dqn-steps", "60", "--no-fp32", "--no-cpu-baseline", "--no-clock-probe", "--no-live-traffic"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and "force_dist" in line and "nccl" in line["force_dist"]
+    assert line["value"] > 0 and line["dqn"]["value"] > 0
+    assert line["dqn"]["collective"].startswith("RCCL all-reduce")
+    assert line["dqn"]["collectives"]["backend"]["us_per_step"] > 0
