@@ -418,7 +418,7 @@ def net_chunk(args):
 
 def bench_fp32(args, dev, tf, tp, scores16, pick, precision="fp32"):
     """The modes that meet north_star's 1e-4 on the same batch: "fp32" (exact fp32 MFMA: the parity gate) and "bf16x3" (fp32 tensors, every
-    contraction behind the stem as three bf16 MFMA passes on hi / lo splits, IVOSW_F32X3) — timed, checked against the oracle at 1e-4, and
+    contraction, the stem included, as three bf16 MFMA passes on hi / lo splits, IVOSW_F32X3) — timed, checked against the oracle at 1e-4, and
     compared with the bf16 scores."""
     from ivos_w_amd.models.assessment import AssessNet
     net = AssessNet(precision=precision)

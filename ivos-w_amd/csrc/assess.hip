@@ -170,6 +170,25 @@ static size_t carve(Arena& ar, int dtype, int B, int c0, Bufs* out) {
 
 using namespace ivosw;
 
+// Which precision an arena was packed for (IVOSW_F32 and IVOSW_F32X3 share plan, sizes and layout, but the x3 pack
+// rewrites every weight K-tile in place as [hi | lo] bf16 - a forward call with the other dtype passed every check and returned
+// garbage).  The tag lives in two places: float slot 6 of the arena's 8-float normalisation block (for whoever inspects or copies
+// an arena) and a host-side table keyed by the arena's address, which the forward entry points check without touching the device.
+static std::mutex g_pack_mu;
+static std::vector<std::pair<const void*, int>> g_pack_dtype;
+static void pack_dtype_record(const void* packed, int dtype) {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    for (auto& e : g_pack_dtype)
+        if (e.first == packed) { e.second = dtype; return; }
+    g_pack_dtype.emplace_back(packed, dtype);
+}
+static int pack_dtype_lookup(const void* packed) {           // -1: not packed by this process (e.g. a copied arena): not checkable
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    for (auto& e : g_pack_dtype)
+        if (e.first == packed) return e.second;
+    return -1;
+}
+
 extern "C" size_t ivosw_assess_packed_bytes(int dtype) {
     if (dtype != IVOSW_F32 && dtype != IVOSW_BF16 && dtype != IVOSW_F32X3) return 0;
     return plan_for(dtype).total;
@@ -189,6 +208,8 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
     (void)hipMemsetAsync(base + P.zero_off, 0, 256, st);
     hipLaunchKernelGGL(copy_small_kernel, dim3(1), dim3(64), 0, st, T(P.t_mean), 3, T(P.t_std), 3,
                        reinterpret_cast<float*>(base + P.norm_off));
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(base + P.norm_off + 6 * sizeof(float)), 0x49560000 | dtype, 1, st);   // 'IV' | dtype
+    pack_dtype_record(packed, dtype);
     (void)hipMemcpyAsync(base + P.fcw_off, T(P.t_fcw), 2048 * sizeof(float), hipMemcpyDeviceToDevice, st);
     (void)hipMemcpyAsync(base + P.fcb_off, T(P.t_fcb), sizeof(float), hipMemcpyDeviceToDevice, st);
     launch_pack_stem(T(P.t_stem_w3), T(P.t_stem_w1), T(P.t_stem_bn), T(P.t_stem_bn + 1), T(P.t_stem_bn + 2),
@@ -334,6 +355,10 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
     IVOSW_REQUIRE((long)H * W <= INT_MAX, "frame too large (H * W <= INT_MAX)");
     IVOSW_REQUIRE(tap_stage >= 0 && tap_stage <= 8, "tap_stage out of range");
     IVOSW_REQUIRE(tap_stage == 0 || tap_out, "tap_out is null");
+    {
+        const int packed_for = pack_dtype_lookup(packed);
+        IVOSW_REQUIRE(packed_for < 0 || packed_for == dtype, "the arena was packed for another dtype (ivosw_assess_pack's dtype must be the forward call's)");
+    }
     const bool want_split = split_wanted(dtype, B, chunk, tap_stage);
     if (chunk <= 0) chunk = default_chunk(dtype);
     if (chunk > B) chunk = B;

@@ -417,9 +417,16 @@ __global__ __launch_bounds__(512) void bneck_wide_stage_kernel(BneckStageArgs s)
 //   phase B  wave = (channel tile, 8/NG pixel tiles), shifted rows hb + ky*18 + kx of the halo image
 //   phase C  (4C/32)/8 chunks x (8 channel tiles = 8 waves) x 8 pixel tiles, store pass as in the frame kernel
 // LDS: [0, 125952) x ring (3 slots of 41 row groups) -> t1 (C/64 slices x 352 rows) -> t2 (C/64 x 256 rows); staging at 128 KB.
-template <int C>
+// WL (round 5, C = 128): the weight fragments of phases A and B reach the waves THROUGH LDS - one LDS-DMA copy per workgroup, read by
+// the two waves that share a channel tile - instead of each wave streaming its own copy from L2 into registers.  A CU takes only
+// 18 - 25 B/clk through its L1 (profiles/r03_res3_ablation.txt: the 262 KB of phase A's duplicated fragments alone hold its loop at
+// 14.6 k cycles; profiles/r05_gemm_tile_bench.txt), and 426 KB of the 1 855 KB a tile moves were second copies.  Same fragments,
+// same k order: bit-identical to WL = false.  Rings: phase A two 16-KB K-tiles in the (then idle) staging area; phase B two 32-KB
+// double steps in [t1 end, bias block) and the staging area, one workgroup barrier per double step.
+template <int C, bool WL = false>
 __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
     constexpr int CIN = 4 * C, HW = (C == 128) ? 32 : 64, BT = 16, HT = 18, HR = HT * HT, MH = 352, NGA = 41;
+    static_assert(!WL || C == 128, "the LDS weight rings are laid out for C = 128");
     constexpr int TPX = HW / BT, TPF = TPX * TPX;    // tiles per frame edge / per frame
     constexpr int NSL = C / 64, NCT = C / 32, NG = 8 / NCT;
     constexpr int TPG = (11 + NG - 1) / NG;          // pixel tiles per group in phase A (6 | 3), the last group has one less
@@ -452,6 +459,17 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         if (p.ts && tid == 0) p.ts[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    // WL: double step d of phase B = steps 2d, 2d + 1 = 8 consecutive fragments (8 KB) of each of the 4 channel tiles -> ring slot d & 1
+    constexpr int WB0_OFF = NSL * T1S, WB1_OFF = STG_OFF;
+    static_assert(!WL || (WB0_OFF + 32768 <= BIAS_OFF), "phase B weight ring");
+    auto wb_issue = [&](int d) {
+        unsigned char* slot = lds + ((d & 1) ? WB1_OFF : WB0_OFF);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ct = wave >> 1, sub = (wave & 1) * 4 + j;
+            dma16(wfrag(p.fb, ct, 9 * C / 16, d * 8 + sub, lane), slot + (ct * 8 + sub) * 1024);
+        }
+    };
     // (Tried: picking the residual of output chunk 0 out of the ring while its x K-tile is resident in phase A, to save
     // re-reading half of x in phase C — 64 more live registers on top of phase A's 96 accumulator + 32 weight registers
     // = 141 VGPR spills.  Dropped.)
@@ -488,9 +506,19 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         };
         u32x4 wq[2][4];
         auto load_w = [&](int kt, int set) {
+            if constexpr (WL) {
+                // K-tile kt of all NCT channel tiles = 16 fragments = 16 KB into ring slot kt & 1: wave w copies fragments (ct = w >> 1,
+                // ks = 2 (w & 1), + 1); the queue order W(kt + 1) | X(kt + 2) per iteration is that of the register path
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, ctw, CIN / 16, kt * 4 + ks, lane)) : "memory");
+                for (int j = 0; j < 2; ++j) {
+                    const int ct = wave >> 1, ks = (wave & 1) * 2 + j;
+                    dma16(wfrag(p.fa, ct, CIN / 16, kt * 4 + ks, lane), lds + STG_OFF + (kt & 1) * 16384 + (ct * 4 + ks) * 1024);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wq[set][ks]) : "v"(wfrag(p.fa, ctw, CIN / 16, kt * 4 + ks, lane)) : "memory");
+            }
         };
         const int pt0 = grp * TPG;                   // pixel tiles pt0 .. ; the last group lacks its final tile (there are 11)
         const bool full = grp + 1 < NG;
@@ -521,6 +549,11 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                 if constexpr (TPG == 6) { one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{}); }
                 static_assert(TPG == 3 || TPG == 6, "tile offsets are immediates");
             };
+            if constexpr (WL) {                      // this wave's four fragments of the K-tile: issued first, so every counted wait below covers them
+                const unsigned wa = lds_base + STG_OFF + (kt & 1) * 16384 + ctw * 4096 + lane * 16;
+                wq[par][0] = lds_read_b128_o<0>(wa); wq[par][1] = lds_read_b128_o<1024>(wa);
+                wq[par][2] = lds_read_b128_o<2048>(wa); wq[par][3] = lds_read_b128_o<3072>(wa);
+            }
             rd(0, 0);
             rd(0, 1);
 #pragma unroll
@@ -540,8 +573,15 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         __builtin_amdgcn_s_barrier();                // the ring is dead: its space becomes t1
         asm volatile("" ::: "memory");
         stamp(1);
+        if constexpr (WL) {
+            // phase B's first two double steps go out under the t1 epilogue: slot 0 = [t1 end, bias block) - part of the x ring until
+            // the barrier above -, slot 1 = the staging area (phase A's weight ring, dead as well)
+            wb_issue(0);
+            wb_issue(1);
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, 9 * C / 16, ks, lane);
+            for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, 9 * C / 16, ks, lane);
+        }
         float4 bq[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4*>(lds + BIAS_OFF + (ctw * 32 + 8 * g + 4 * lhalf) * 4);
@@ -586,11 +626,26 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
         for (int step = 0; step < NSTEP; ++step) {   // step = tap * NSL + slice
             const int tap = step / NSL, sl = step - tap * NSL;
             u32x4 wc[4];
+            if constexpr (WL) {
+                static_assert(!WL || NSTEP % 2 == 0, "double steps");
+                if ((step & 1) == 0) {
+                    // double step d: this wave's pieces of it have landed (only d + 1's four may be younger - in the first round; later
+                    // d + 1 is issued behind this barrier), the barrier publishes it and frees the slot of d - 1 for d + 1
+                    const int d = step >> 1;
+                    if (d == 0) wait_vmcnt<4>(); else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (d >= 1 && 2 * (d + 1) < NSTEP) wb_issue(d + 1);
+                }
+                const unsigned wa = lds_base + (((step >> 1) & 1) ? WB1_OFF : WB0_OFF) + (ctw * 8 + (step & 1) * 4) * 1024 + lane * 16;
+                wc[0] = lds_read_b128_o<0>(wa); wc[1] = lds_read_b128_o<1024>(wa); wc[2] = lds_read_b128_o<2048>(wa); wc[3] = lds_read_b128_o<3072>(wa);
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
-            if (step + 1 < NSTEP) {
+                for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+                if (step + 1 < NSTEP) {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
+                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
+                }
             }
             unsigned rowa[PB], rkey[PB];
 #pragma unroll
@@ -2045,6 +2100,7 @@ void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.ds ? nullptr : a.x;
     void* tok = prof_begin(d, 2, st);
     if (a.Cmid == 128 && tune_get("HALO128S", 0)) hipLaunchKernelGGL(bneck_halo128s_kernel, dim3(a.B * 8), dim3(512), 0, st, a);
+    else if (a.Cmid == 128 && tune_get("HALO_WLDS", 1)) hipLaunchKernelGGL((bneck_halo_kernel<128, true>), dim3(a.B * 4), dim3(512), 0, st, a);
     else if (a.Cmid == 128) hipLaunchKernelGGL((bneck_halo_kernel<128>), dim3(a.B * 4), dim3(512), 0, st, a);
     else if (a.ds && a.t1out && a.nd == 64) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 64>), dim3(a.B * 32), dim3(512), 0, st, a);
     else if (a.ds) hipLaunchKernelGGL((bneck_halo64s_kernel<true, false, 0>), dim3(a.B * 32), dim3(512), 0, st, a);

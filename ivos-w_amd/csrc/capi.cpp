@@ -37,11 +37,18 @@ DeviceScope::~DeviceScope() {
 }  // namespace ivosw
 
 namespace ivosw {
-// Tunables: fixed table, looked up by name.  Lookups and first-use insertion are safe from several host threads; two threads SETTING the same key
-// race on its value like any unsynchronised int (tuning / test hook).
+// Tunables: fixed table, looked up by name.  Lookups, first-use insertion, tune_set and the one-time environment read are safe from
+// several host threads: a SET value and the cached environment default live in separate atomic fields, so a lookup
+// that is reading the environment can never overwrite a concurrent tune_set; the flags are published with release / acquire.
 // The sources read 47 distinct keys (grep tune_get); the table holds every one of them set at once plus a cache entry per key
 // for the environment default (IVOSW_TUNE_<KEY> is read ONCE per key and process: a forward pass asks for ~40 keys).
-struct Tunable { char key[32]; int value; bool set, env_read, env_has; };
+struct Tunable {
+    char key[32];
+    std::atomic<int> value;          // ivosw_tune_set
+    std::atomic<int> env_value;      // IVOSW_TUNE_<KEY>, read once
+    std::atomic<bool> set;
+    std::atomic<int> env_state;      // 0 not read yet, 1 absent, 2 present
+};
 constexpr int kMaxTunables = 160;
 static_assert(kMaxTunables >= 3 * 47, "the tunables table must hold every key the sources read, with room to grow");
 static Tunable g_tun[kMaxTunables];
@@ -62,8 +69,10 @@ static Tunable* tune_find(const char* key, bool create) {
     if (m >= kMaxTunables) return nullptr;
     Tunable* t = &g_tun[m];
     strcpy(t->key, key);
-    t->value = 0;
-    t->set = t->env_read = t->env_has = false;
+    t->value.store(0, std::memory_order_relaxed);
+    t->env_value.store(0, std::memory_order_relaxed);
+    t->set.store(false, std::memory_order_relaxed);
+    t->env_state.store(0, std::memory_order_relaxed);
     g_ntun.store(m + 1, std::memory_order_release);
     return t;
 }
@@ -76,16 +85,17 @@ int tune_get(const char* key, int dflt) {
         const char* e = getenv(env);
         return e ? atoi(e) : dflt;
     }
-    if (t->set) return t->value;
-    if (!t->env_read) {
+    if (t->set.load(std::memory_order_acquire)) return t->value.load(std::memory_order_relaxed);
+    int st = t->env_state.load(std::memory_order_acquire);
+    if (st == 0) {                                   // several threads may get here together: they all compute the same two values
         char env[64];
         snprintf(env, sizeof(env), "IVOSW_TUNE_%s", key);
         const char* e = getenv(env);
-        t->env_has = e != nullptr;
-        if (e) t->value = atoi(e);
-        t->env_read = true;
+        if (e) t->env_value.store(atoi(e), std::memory_order_relaxed);
+        st = e ? 2 : 1;
+        t->env_state.store(st, std::memory_order_release);
     }
-    return t->env_has ? t->value : dflt;
+    return st == 2 ? t->env_value.load(std::memory_order_relaxed) : dflt;
 }
 }  // namespace ivosw
 
@@ -94,8 +104,8 @@ extern "C" int ivosw_tune_set(const char* key, int value) {
     IVOSW_REQUIRE(key && strlen(key) < sizeof(g_tun[0].key), "bad key");
     Tunable* t = tune_find(key, true);
     IVOSW_REQUIRE(t != nullptr, "tunable table full");
-    t->value = value;
-    t->set = true;
+    t->value.store(value, std::memory_order_relaxed);
+    t->set.store(true, std::memory_order_release);
     return IVOSW_OK;
 }
 

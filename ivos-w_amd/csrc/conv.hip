@@ -97,6 +97,9 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
 // activations from 16-byte chunks 4 s + 2 h and 4 s + 2 h + 1 (eight floats, split here: hi = truncation — one v_perm per pair —,
 // lo = RNE(x - hi), exact difference), weights from chunk 2 s + h (hi) and 4 + 2 s + h (lo).  Three products per operand pair:
 // ah bh + ah bl + al bh; the dropped al bl is ~ 2^-17 of the product, like the rounding of the lo parts.
+// Special values: x = +-Inf splits into hi = +-Inf, lo = Inf - Inf = NaN, so an activation that OVERFLOWED to
+// infinity comes out of this mode as NaN where the fp32 mode keeps Inf; NaN stays NaN in both.  Finite inputs are unaffected; the
+// mode promises no Inf-propagation parity (three more VALU instructions per pair in a VALU-bound body would buy it).
 __device__ __forceinline__ void split8_x3(const u32x4& c0, const u32x4& c1, u32x4& hi, u32x4& lo) {
     const unsigned x[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
 #pragma unroll

@@ -28,7 +28,8 @@ struct P2pHeader {                 // at the start of every arena
     unsigned flags[2][64];         // [parity][source rank]: last epoch whose data from that rank is complete
     unsigned ticket;               // workgroups of the running push that are done (0 between launches)
     unsigned error;                // set by reduce on timeout
-    unsigned pad[62];
+    unsigned verdict;              // (epoch << 2) | 1 = every workgroup applies this epoch, | 2 = none does: decided ONCE per epoch by compare-and-swap
+    unsigned pad[61];
 };
 static_assert(sizeof(P2pHeader) % 256 == 0, "slots stay 256-byte aligned");
 constexpr int P2P_MAX_WORLD = 64;
@@ -67,34 +68,41 @@ __global__ __launch_bounds__(1024) void p2p_push_kernel(const float* __restrict_
     }
 }
 
-// Wait for the `world` flags of this epoch.  The verdict is GRID-WIDE (with one deadline per workgroup, a peer
-// arriving near it let some workgroups apply their slice of clamp + Adam while others returned): only workgroup 0 declares a
-// timeout (it sets the arena's error word); every other workgroup spins until it sees all flags — then proceeds only if the
-// error word is still clear — or until it sees the error word.  Flags are monotonic within an epoch, so whenever any workgroup
-// saw them all before workgroup 0's deadline, workgroup 0 sees them too and never declares; if it declared first, latecomers find
-// the word set.  Either every workgroup applies or none does.  (A second bound of 2 x the timeout keeps a workgroup from spinning
-// forever should workgroup 0 never run; it sets the word too.)
+// Wait for the `world` flags of this epoch.  The verdict is GRID-WIDE and decided ONCE per epoch through one word (ADVICE round 4:
+// the round-3 form - workgroup 0 alone declares a timeout through the error word - left a window between its lane's deadline and
+// the word's publication in which a late flag let other workgroups apply their slice of clamp + Adam): a workgroup that saw every
+// flag proposes (epoch, OK), a workgroup whose deadline passed proposes (epoch, TIMEOUT), both by atomicCAS on h->verdict, and EVERY
+// workgroup acts on the value that is in the word afterwards - the first proposal wins for the whole grid, so either every workgroup
+// applies its slice or none does.  Deadlines: workgroup 0 after the timeout, the others after twice that (should workgroup 0 never
+// run).  A TIMEOUT verdict also sets the sticky error word the host reads.
 __device__ __forceinline__ bool p2p_wait_all(P2pHeader* h, int world, int parity, unsigned epoch, unsigned long long timeout_ticks) {
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
+    __shared__ int state;                                    // 0 undecided here, 1 all flags seen, 2 timed out / verdict already there
+    if (threadIdx.x == 0) state = 1;
     __syncthreads();
     if ((int)threadIdx.x < world) {                          // lane s waits for rank s
         const unsigned long long t0 = wall_clock64();
         const unsigned long long limit = blockIdx.x == 0 ? timeout_ticks : 2 * timeout_ticks;
         while (__hip_atomic_load(&h->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            if (wall_clock64() - t0 > limit || __hip_atomic_load(&h->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+            const unsigned w = __hip_atomic_load(&h->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wall_clock64() - t0 > limit || (w >> 2) == epoch) { state = 2; break; }
             __builtin_amdgcn_s_sleep(8);
         }
     }
     __syncthreads();
-    if (!bad && threadIdx.x == 0 && __hip_atomic_load(&h->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) bad = 1;
+    if (threadIdx.x == 0) {
+        const unsigned mine = (epoch << 2) | (state == 1 ? 1u : 2u);
+        unsigned w = __hip_atomic_load(&h->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((w >> 2) != epoch) {                          // undecided for this epoch: propose; whoever swaps first has decided
+            const unsigned seen = atomicCAS(&h->verdict, w, mine);
+            if (seen == w) { w = mine; break; }
+            w = seen;
+        }
+        state = (w & 3u) == 1u ? 1 : 2;
+        if (state == 2) atomicExch(&h->error, 1u);
+    }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope: nothing cached from the slots' previous contents
-    if (bad) {
-        if (threadIdx.x == 0) atomicExch(&h->error, 1u);
-        return false;
-    }
-    return true;
+    return state == 1;
 }
 
 __global__ __launch_bounds__(1024) void p2p_reduce_kernel(float* __restrict__ out, int n, int world, void* arena, unsigned epoch,

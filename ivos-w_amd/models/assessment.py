@@ -10,7 +10,7 @@ Same class surface and ``state_dict`` (326 tensors) as /root/reference/models/as
 The torch modules below are parameter containers only (keys, shapes, checkpoint I/O); torchvision is not
 needed and nothing is downloaded.  ``precision='fp32'`` (default) is the parity mode (fp32 MFMA, scores within
 1e-4 rtol of the reference CPU path); ``precision='bf16x3'`` keeps fp32 tensors and the 1e-4 bar but runs every contraction
-behind the stem as three bf16 MFMA passes on (hi, lo) splits (a b ~ ah bh + ah bl + al bh: error ~ 2^-17 per product, 16 / 3 of
+- the stem included - as three bf16 MFMA passes on (hi, lo) splits (a b ~ ah bh + ah bl + al bh: error ~ 2^-17 per product, 16 / 3 of
 the fp32 matrix rate); ``precision='bf16'`` is the throughput mode (bf16 operands, fp32 accumulate).
 Inference only (eval-mode BatchNorm): AssessNet training is outside the hot path.
 """

@@ -132,3 +132,34 @@ def test_stage_kernel_isa_has_no_use_of_an_in_flight_asm_ds_read(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     s = subprocess.run([sys.executable, os.path.join(root, "tools", "asm_inflight_scan.py"), asm], capture_output=True, text=True, timeout=300)
     assert s.returncode == 0 and "res2_stage_kernel" in s.stdout, s.stdout[-2000:]
+
+
+def test_shipped_kernels_scratch_budget():
+    """scratch spills in the hot kernels mean a compiler update can move their timing unnoticed.  The figures are read
+    from the code objects inside the SHIPPED library (tools/kernel_resources.py: no compile).  Every kernel must be spill-free except the
+    ones listed here with their present counts (all of them loop-invariant addresses parked in the prologue and reloaded at phase
+    boundaries, never inside a k-loop) - a RATCHET: a count may shrink, never grow, and no new kernel may start spilling.  The one-wave-per-SIMD
+    kernels must really have their accumulators in AGPRs."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    table = kr.kernel_table()
+    assert len(table) > 40
+    allowed = {                                       # substring of the mangled name -> ceiling
+        "res2_stage_kernelILb1ELi0": 10, "res2_stage_kernelILb0ELi0": 10, "stage_first_kernel": 23, "bneck_wide_stage_kernelILi256ELi16ELi1": 25,
+        "bneck_wide_kernelILi256ELi16ELi1": 1, "bneck_halo64s_kernelILb1ELb0ELi64ELb0": 1, "bneck_halo128s_kernel": 31,
+        "conv_igemm_ws_kernelIfLi4ELi2ELi2ELi2ELi3ELi8ELb1": 1,
+    }
+    over = {}
+    for name, r in table.items():
+        cap = max([v for k, v in allowed.items() if k in name] or [0])
+        if r["spill"] > cap:                          # (SGPR spills go to VGPR lanes, not to memory: not counted)
+            over[name] = (r["spill"], cap)
+        assert r["lds"] <= 163840 and r["vgpr"] <= 512
+    assert not over, over
+    # the default-path kernels this round touched: spill-free
+    for key in ("bneck_halo_kernelILi128ELb1", "bneck_halo_kernelILi128ELb0", "conv1x1_wide_kernel"):
+        hits = [r for n, r in table.items() if key in n]
+        assert hits and all(r["spill"] == 0 and r["scratch"] == 0 for r in hits), key

@@ -684,6 +684,25 @@ def test_res3_small_tile_kernel_is_bit_identical(dev, net16):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 
 
+def test_res3_weights_through_lds_are_bit_identical(dev, net16):
+    """Round 5: res3's identity blocks take their phase A / B weight fragments from ONE LDS-DMA copy per workgroup (bneck_halo_kernel<128, true>,
+    tunable HALO_WLDS=1, the default) instead of one register stream per wave (HALO_WLDS=0): the same fragments in the same K order, so the res3
+    output and the scores must agree bit for bit - full, odd and chunked batches, frames at the batch edge."""
+    from ivos_w_amd import _lib as L
+    for B, edge, chunk in ((8, True, 0), (3, False, 0), (5, False, 2)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
+        got = {}
+        try:
+            for mode in (0, 1):
+                L.tune_set(b"HALO_WLDS", mode)
+                got[mode] = [net.forward_tap(ttf, ttp, "res3")[1].clone(), net(ttf, ttp).clone()]
+        finally:
+            L.tune_set(b"HALO_WLDS", 1)
+        for a, b, nm in zip(got[1], got[0], ("res3", "scores")):
+            assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
+
+
 def test_res4_half_frame_kernel_is_bit_identical(dev, net16):
     """Small launches (<= HALF16_MAX = 96 frames) run res4's identity blocks on 8 x 16-pixel half frames (bneck_half16_kernel, two
     workgroups per frame) instead of one frame per workgroup: the same MFMAs in the same K order per output pixel, so the res4
@@ -702,3 +721,24 @@ def test_res4_half_frame_kernel_is_bit_identical(dev, net16):
             L.tune_set(b"HALF16_MAX", 96)
         for a, b, nm in zip(got[96], got[0], ("res4", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
+
+
+def test_forward_refuses_an_arena_packed_for_another_dtype(dev):
+    """IVOSW_F32 and IVOSW_F32X3 arenas have the same size and layout, but the x3 pack rewrites every weight K-tile as
+    [hi | lo] bf16 - forwarding one with the other dtype used to pass every check and return garbage.  The library now remembers what an
+    arena was packed for and the forward entry points refuse a mismatch (C ABI users; the Python wrapper keys its cache on precision)."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    net = make_net(dev, "bf16x3")
+    _, _, ttf, ttp = inputs(dev, 2, False)
+    want = net(ttf, ttp).clone()
+    packed = net._ensure_packed()
+    B, _, H, W = ttf.shape
+    for wrong in (L.F32, L.BF16):
+        nbytes = lib.ivosw_assess_ws_bytes(wrong, B, H, W, 0)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        scores = torch.empty(B, dtype=torch.float32, device=dev)
+        rc = lib.ivosw_assess_forward(L.dptr(packed), wrong, L.dptr(ttf), L.dptr(ttp), B, H, W, L.dptr(scores), L.dptr(ws), nbytes, 0, 0, None,
+                                      L.stream_ptr(dev))
+        assert rc != 0 and b"packed for another dtype" in lib.ivosw_last_error()
+    assert torch.equal(net(ttf, ttp), want)                 # the right dtype still runs
