@@ -184,6 +184,31 @@ def check_scores(scores, tf, tp, precision, pick):
     return {"frames": len(pick), "worst_rel_err": float(f"{err:.3e}"), "tolerance": tol, "against": "oracle/assess_oracle.py (torch-CPU restatement of AssessNet.forward)"}
 
 
+def dqn_dp_critical_path(single_us, timeout_s=150):
+    """The left-hand side of DESIGN section 6's scaling budget, measured: the SAME DQN step run in a child process
+    through the N > 1 branch on the backend that the multi-GPU job uses (`--gpus 1 --force-dist`: a process group of one rank on nccl = RCCL;
+    gradients -> dist.all_reduce of the 724 KB arena on the compute stream -> clamp + Adam with 1/world, plain launches), against the
+    fused single-GPU step of this run.  Their difference is what data parallelism adds to a step before any wire time: the launch gaps of
+    the un-fused structure, RCCL's kernel for a one-rank communicator and the separate clamp + Adam.  None when the child fails."""
+    import subprocess
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--workload", "dqn", "--steps", "1500", "--warmup", "50",
+           "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        dp_us = float(line["collectives"]["backend"]["us_per_step"])
+    except Exception:
+        return None
+    return {"us_per_step_through_the_collective_branch": dp_us, "us_per_step_fused_single_gpu": round(single_us, 1),
+            "added_by_the_data_parallel_structure_us": round(dp_us - single_us, 1),
+            "budget_us_for_6x_at_8_gpus": round(single_us * (8.0 / 6.0 - 1.0), 1),
+            "how": "child run `bench.py --gpus 1 --force-dist --workload dqn`: process group of ONE rank on nccl (RCCL), all-reduce of the 724 KB "
+                   "gradient arena + clamp + Adam as plain launches; wire time between GPUs is NOT in it (no second GPU on this box)"}
+
+
 def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=75):
     """roofline.traffic measured in THIS run: the same forward (batch 256, bf16, default chunk) is re-run in two child processes
     under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only - no trace domains), after the
@@ -945,6 +970,8 @@ def main():
         line["cpu_baseline"] = cpu_baseline_assess() if args.workload == "assess" else cpu_baseline_dqn()
         if args.workload == "assess":
             line["dqn"]["cpu_baseline"] = cpu_baseline_dqn()
+            if not FORCE_DIST[0]:
+                line["dqn"]["dp_critical_path"] = dqn_dp_critical_path(line["dqn"]["us_per_step"])
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -404,7 +404,10 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     Bufs bf{};
     carve(ar, dtype, B, chunk, &bf);
     auto tap = [&](int stage, const void* src, size_t bytes) {
-        if (tap_stage == stage) (void)hipMemcpyAsync(tap_out, src, bytes, hipMemcpyDeviceToDevice, st);
+        if (tap_stage != stage) return;
+        (void)hipMemcpyAsync(tap_out, src, bytes, hipMemcpyDeviceToDevice, st);
+        // IVOSW_F32X3 keeps its activations (stem output .. res5) in the split hi | lo layout: the tap hands out plain fp32
+        if (dtype == IVOSW_F32X3 && stage >= 2 && stage <= 7) launch_unsplit_x3(tap_out, bytes / sizeof(float), st);
     };
 
     // K1/K2: mask -> (y,x,h,w) for the whole batch, on device

@@ -20,12 +20,16 @@ struct ConvArgs {
     int nt;             // bit 0: non-temporal output stores, bit 1: non-temporal residual loads (generic epilogue), bit 2: also in the patch / fused kernels (tunable NT, default 3)
     int debug;          // ablation bits (IVOSW_DEBUG_CONV, tuning only): 1 skip epilogue stores, 2 skip MFMA, 4 skip DMA after the first tile
     int rev;            // 1: pixel tiles are taken in DESCENDING order (see BneckWideArgs::rev; tunable SNAKE)
-    int x3;             // fp32 tensors, contraction as three bf16 MFMA passes (IVOSW_F32X3): w is the PRE-SPLIT weight array
+    int x3;             // IVOSW_F32X3: contraction as three bf16 MFMA passes, w is the PRE-SPLIT weight array; 2 (what launch_conv sets):
+                        // activations are stored split as well - [32 x bf16 hi | 32 x bf16 lo] per 32-channel group, the bytes of 32 floats -
+                        // by every epilogue and read without VALU work by every consumer except the stem (fp32 ROI tile)
 };
 
 void launch_conv(const ConvArgs& a, int dtype, bool stem, hipStream_t st);
 // in place: every 32-float K-tile of w [rows][K] (128 bytes) becomes [32 x bf16 hi | 32 x bf16 lo], hi = RNE(w), lo = RNE(w - hi)
 void launch_split_weights_x3(void* w, long rows, int K, hipStream_t st);
+// split activation layout -> plain fp32, in place (test taps of the IVOSW_F32X3 mode); nfloats % 32 == 0
+void launch_unsplit_x3(void* buf, size_t nfloats, hipStream_t st);
 
 // res3's first bottleneck behind its conv1 (3x3 stride 2, then [conv3 | downsample]) as one launch, bf16 (stage_first.hip)
 struct StageFirstArgs {

@@ -26,6 +26,18 @@
 namespace ivosw {
 
 
+// eight fp32 values -> four packed bf16 hi pairs (truncation: the top halves) and four packed lo pairs (RNE(x - hi), an exact
+// difference): the producer-side split of the IVOSW_F32X3 activation format, ~3 VALU per value ONCE instead of 24 per 8-float
+// fragment in every wave that consumes it
+__device__ __forceinline__ void split8_store_x3(const float (&v)[8], uint32_t (&hi)[4], uint32_t (&lo)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned a = __float_as_uint(v[2 * q]), b = __float_as_uint(v[2 * q + 1]);
+        hi[q] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+        lo[q] = pack2_bf16(v[2 * q] - __uint_as_float(a & 0xffff0000u), v[2 * q + 1] - __uint_as_float(b & 0xffff0000u));
+    }
+}
+
 // epilogue phase 2: 8 consecutive channels per thread: + bias (+ residual) -> ReLU -> 16/32-B stores
 template <typename T, int BM, int BN, int NT = 256, bool PRE = false>
 __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* Cs, int m0, int n0, int M, int tid,
@@ -74,6 +86,31 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
             } else {
                 *reinterpret_cast<uint4*>(Y + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
+        } else if (p.x3 == 2) {
+            // IVOSW_F32X3 activations are stored SPLIT (round 5): a 32-channel group is 128 bytes, [32 x bf16 hi | 32 x bf16 lo] - the
+            // bytes of 32 floats, so every offset, K-tile and DMA piece of the fp32 layout stays what it is.  This thread's 8 channels
+            // are 16-byte chunk c of the group: hi at chunk c, lo at chunk 4 + c
+            const long og = (long)m * p.Cout + (n & ~31);                      // in floats
+            const int c = (n & 31) >> 3;
+            const uint4* rs = reinterpret_cast<const uint4*>(R + og);
+            if (R) {
+                const uint4 rh = rs[c], rl = rs[4 + c];
+                const uint32_t h4[4] = {rh.x, rh.y, rh.z, rh.w}, l4[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += __uint_as_float(h4[q] << 16) + __uint_as_float(l4[q] << 16);
+                    v[2 * q + 1] += __uint_as_float(h4[q] & 0xffff0000u) + __uint_as_float(l4[q] & 0xffff0000u);
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            uint32_t hi[4], lo[4];
+            split8_store_x3(v, hi, lo);
+            uint4* ys = reinterpret_cast<uint4*>(Y + og);
+            ys[c] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            ys[4 + c] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         } else {
             if (R) {
                 const float4 r0v = *reinterpret_cast<const float4*>(R + o);
@@ -110,14 +147,16 @@ __device__ __forceinline__ void split8_x3(const u32x4& c0, const u32x4& c1, u32x
         lo[q] = pack2_bf16(l0, l1);
     }
 }
-template <int TM, int TN>
+// PRE: the activation K-tile is already in the split layout (every layer behind the stem: epilogue_store writes it) - hi and lo
+// fragments are read like the weights', no VALU; !PRE (the stem, whose operand is gathered from the fp32 ROI tile): split here.
+template <int TM, int TN, bool PRE>
 __device__ __forceinline__ void ktile_mma_x3(f32x16 (&acc)[TM][TN], unsigned a_base, unsigned b_base, int wm, int wn, int lrow, int lhalf) {
     u32x4 a0[2][TM], a1[2][TM], bh[2][TN], bl[2][TN];
     auto frag_read = [&](int s, int buf) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            a0[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, 4 * s + 2 * lhalf));
-            a1[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, 4 * s + 2 * lhalf + 1));
+            a0[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, PRE ? 2 * s + lhalf : 4 * s + 2 * lhalf));
+            a1[buf][i] = lds_read_b128(a_base + swz((wm * TM + i) * 32 + lrow, PRE ? 4 + 2 * s + lhalf : 4 * s + 2 * lhalf + 1));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -132,7 +171,10 @@ __device__ __forceinline__ void ktile_mma_x3(f32x16 (&acc)[TM][TN], unsigned a_b
         if (s < 1) frag_read(1, 1);
         u32x4 ah[TM], al[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) split8_x3(a0[s][i], a1[s][i], ah[i], al[i]);
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (PRE) { ah[i] = a0[s][i]; al[i] = a1[s][i]; }
+            else split8_x3(a0[s][i], a1[s][i], ah[i], al[i]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -259,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         const unsigned char* Bs = As + BM * ROWB;
         if constexpr (X3) {
             const unsigned lb = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds + buf * STAGE_BYTES;
-            ktile_mma_x3<TM, TN>(acc, lb, lb + BM * ROWB, wm, wn, lrow, lhalf);
+            ktile_mma_x3<TM, TN, !STEM>(acc, lb, lb + BM * ROWB, wm, wn, lrow, lhalf);
         } else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -441,7 +483,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_dma_kernel(
         if (kt + S - 1 < nk && !ABL(p.debug, 4)) issue(kt + S - 1, fill);   // refill the slot tile kt-1 just vacated
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
         if constexpr (X3) {
-            ktile_mma_x3<TM, TN>(acc, a_base, b_base, wm, wn, lrow, lhalf);
+            ktile_mma_x3<TM, TN, true>(acc, a_base, b_base, wm, wn, lrow, lhalf);
             stage = (stage + 1 == S) ? 0 : stage + 1;
             fill = (fill + 1 == S) ? 0 : fill + 1;
             continue;
@@ -636,7 +678,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
         if ABL(p.debug, 8) continue;                   // ablation: loaders + barriers only (pure fill rate of the real access pattern)
         const unsigned a_base = lds_base + stage * STAGE_BYTES, b_base = a_base + BM * ROWB;
         if constexpr (X3) {
-            ktile_mma_x3<TM, TN>(acc, a_base, b_base, wm, wn, lrow, lhalf);
+            ktile_mma_x3<TM, TN, true>(acc, a_base, b_base, wm, wn, lrow, lhalf);
             stage = (stage + 1 == S) ? 0 : stage + 1;
             continue;
         }
@@ -1029,7 +1071,7 @@ void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
         a.nmajor = (nm == 1) || (nm == 2 && a.KH == 3);
         a.nt = tune_get("NT", 3);   // streaming tensors are far larger than L2: keep them from evicting the A / weight lines that ARE reused
     }
-    a.x3 = dtype == IVOSW_F32X3 ? 1 : 0;
+    a.x3 = dtype == IVOSW_F32X3 ? 2 : 0;         // 2: activations in the split layout (every output; every input except the stem's ROI tile)
     void* tok = prof_begin(a, (dtype == IVOSW_BF16) ? 2 : 4, st);
     if (dtype == IVOSW_BF16) {
         if (stem) launch_conv_t<bf16_t, true>(a, st); else launch_conv_t<bf16_t, false>(a, st);
@@ -1194,8 +1236,79 @@ __global__ void maxpool_kernel(const T* __restrict__ x, int B, int H, int W, int
     }
 }
 
+// the same on the split activation layout of IVOSW_F32X3 ([32 x bf16 hi | 32 x bf16 lo] per 32-channel group): a thread takes the 8
+// channels of one 16-byte chunk, compares the reconstructed values (hi + lo is exact in fp32) and re-splits the maxima
+__global__ void maxpool_x3_kernel(const uint4* __restrict__ x, int B, int H, int W, int C, uint4* __restrict__ y) {
+    const int Ho = H / 2, Wo = W / 2, CG = C / 8, G8 = C / 32 * 8;      // uint4 chunks per pixel: 8 per 32-channel group
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * Ho * Wo * CG) return;
+    const int cg = (int)(i % CG);
+    long t = i / CG;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const int ch = (cg >> 2) * 8 + (cg & 3);                            // hi chunk of this thread's channels; lo = + 4
+    float m[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int iy = oy * 2 - 1 + dy;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ix = ox * 2 - 1 + dx;
+            if (ix < 0 || ix >= W) continue;
+            const uint4* px = x + (((long)b * H + iy) * W + ix) * G8;
+            const uint4 vh = px[ch], vl = px[ch + 4];
+            const uint32_t h4[4] = {vh.x, vh.y, vh.z, vh.w}, l4[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                m[2 * q] = fmaxf(m[2 * q], __uint_as_float(h4[q] << 16) + __uint_as_float(l4[q] << 16));
+                m[2 * q + 1] = fmaxf(m[2 * q + 1], __uint_as_float(h4[q] & 0xffff0000u) + __uint_as_float(l4[q] & 0xffff0000u));
+            }
+        }
+    }
+    uint32_t hi[4], lo[4];
+    split8_store_x3(m, hi, lo);
+    uint4* o = y + (((long)b * Ho + oy) * Wo + ox) * G8;
+    o[ch] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    o[ch + 4] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+// split layout -> plain fp32, in place (the test taps of the IVOSW_F32X3 mode): one thread per 32-channel group
+__global__ void unsplit_x3_kernel(uint4* __restrict__ buf, long ngroups) {
+    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    uint4* p = buf + g * 8;
+    uint4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = p[c];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t h4[4] = {v[c].x, v[c].y, v[c].z, v[c].w}, l4[4] = {v[4 + c].x, v[4 + c].y, v[4 + c].z, v[4 + c].w};
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f[2 * q] = __uint_as_float(h4[q] << 16) + __uint_as_float(l4[q] << 16);
+            f[2 * q + 1] = __uint_as_float(h4[q] & 0xffff0000u) + __uint_as_float(l4[q] & 0xffff0000u);
+        }
+        float4* o = reinterpret_cast<float4*>(p) + 2 * c;
+        o[0] = make_float4(f[0], f[1], f[2], f[3]);
+        o[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+}
+
+void launch_unsplit_x3(void* buf, size_t nfloats, hipStream_t st) {
+    const long ng = (long)(nfloats / 32);
+    hipLaunchKernelGGL(unsplit_x3_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, static_cast<uint4*>(buf), ng);
+}
+
 void launch_maxpool(const void* x, int B, int H, int W, int C, int dtype, void* y, hipStream_t st) {
-    if (dtype == IVOSW_BF16) {
+    if (dtype == IVOSW_F32X3) {
+        const long n = (long)B * (H / 2) * (W / 2) * (C / 8);
+        hipLaunchKernelGGL(maxpool_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const uint4*>(x), B, H, W, C, static_cast<uint4*>(y));
+    } else if (dtype == IVOSW_BF16) {
         const long n = (long)B * (H / 2) * (W / 2) * (C / 8);
         hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const bf16_t*>(x), B, H, W, C, static_cast<bf16_t*>(y));
     } else {
@@ -1205,7 +1318,7 @@ void launch_maxpool(const void* x, int B, int H, int W, int C, int dtype, void* 
 }
 
 // ---------------------------------------------------------------- 8x8 average pool + fc (2048 -> 1); one block per frame
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pool_fc_kernel(const T* __restrict__ x, const float* __restrict__ fcw, const float* __restrict__ fcb,
                                                       float* __restrict__ score, float* __restrict__ pooled_out) {
     constexpr int C = 2048, P = 64;
@@ -1215,7 +1328,17 @@ __global__ __launch_bounds__(256) void pool_fc_kernel(const T* __restrict__ x, c
     for (int q = 0; q < 8; ++q) s[q] = 0.f;
     const T* base = x + (long)b * P * C + tid * 8;
     for (int pidx = 0; pidx < P; ++pidx) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (SPLIT) {
+            // channels tid * 8 .. + 7 = chunk tid & 3 of 32-channel group tid >> 2: hi at chunk c, lo at chunk 4 + c of the group's 8
+            const uint4* g = reinterpret_cast<const uint4*>(x + (long)b * P * C + (long)pidx * C) + (tid >> 2) * 8;
+            const uint4 vh = g[tid & 3], vl = g[4 + (tid & 3)];
+            const uint32_t h4[4] = {vh.x, vh.y, vh.z, vh.w}, l4[4] = {vl.x, vl.y, vl.z, vl.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[2 * q] += __uint_as_float(h4[q] << 16) + __uint_as_float(l4[q] << 16);
+                s[2 * q + 1] += __uint_as_float(h4[q] & 0xffff0000u) + __uint_as_float(l4[q] & 0xffff0000u);
+            }
+        } else if constexpr (sizeof(T) == 2) {
             const uint4 v = *reinterpret_cast<const uint4*>(base + (long)pidx * C);
             const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1248,6 +1371,8 @@ void launch_pool_fc(const void* x, int B, int dtype, const float* fcw, const flo
                     hipStream_t st) {
     if (dtype == IVOSW_BF16)
         hipLaunchKernelGGL(pool_fc_kernel<bf16_t>, dim3(B), dim3(256), 0, st, static_cast<const bf16_t*>(x), fcw, fcb, score, pooled);
+    else if (dtype == IVOSW_F32X3)
+        hipLaunchKernelGGL((pool_fc_kernel<float, true>), dim3(B), dim3(256), 0, st, static_cast<const float*>(x), fcw, fcb, score, pooled);
     else
         hipLaunchKernelGGL(pool_fc_kernel<float>, dim3(B), dim3(256), 0, st, static_cast<const float*>(x), fcw, fcb, score, pooled);
 }

@@ -296,27 +296,31 @@ def test_train_agent_data_parallel_under_torchrun(tmp_path):
     assert os.path.isdir(os.path.join(work, "results", "rank1")) and not os.path.exists(os.path.join(work, "results", "rank1", "train_summary.json"))
 
 
-def _rccl_world1_worker(port, q):
-    """ONE rank, backend nccl (= RCCL): communicator creation, dist.all_reduce of the 724 KB gradient arena on the compute stream, the
-    fused clamp + Adam behind it — parallel.data_parallel_step exactly as a rank of the 8-GPU job runs it."""
+def _rccl_world1_worker(port, q, forced):
+    """forced: ONE rank, backend nccl (= RCCL): communicator creation, dist.all_reduce of the 724 KB gradient arena on the compute stream,
+    the fused clamp + Adam behind it — parallel.data_parallel_step exactly as a rank of the 8-GPU job runs it.  not forced: the plain
+    single-process steps, in a fresh process as well (the pytest process may carry tunables of earlier tests)."""
     import io
     import contextlib
     from ivos_w_amd import parallel
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", IVOSW_FORCE_DIST="1",
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", IVOSW_FORCE_DIST="1" if forced else "0",
                       IVOSW_P2P="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r, w, dev = parallel.init("nccl")
-    assert dev.type == "cuda" and w == 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
-    assert parallel.collective_active()
+    assert dev.type == "cuda" and w == 1
     tr = synth.replay_transitions(n=2000, T=25, seed=2019)
     agent = _agent(dev)
-    assert parallel.collective_path(agent.policy_net.flat_grad) == "backend"
     calls = []
-    real = torch.distributed.all_reduce
+    if forced:
+        assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and parallel.collective_active()
+        assert parallel.collective_path(agent.policy_net.flat_grad) == "backend"
+        real = torch.distributed.all_reduce
 
-    def counting(t, *a, **k):
-        calls.append((tuple(t.shape), t.device.type, t.data_ptr()))
-        return real(t, *a, **k)
-    torch.distributed.all_reduce = counting
+        def counting(t, *a, **k):
+            calls.append((tuple(t.shape), t.device.type, t.data_ptr()))
+            return real(t, *a, **k)
+        torch.distributed.all_reduce = counting
+    else:
+        assert not torch.distributed.is_initialized() and not parallel.collective_active()
     np.random.seed(5)
     out = []
     with contextlib.redirect_stdout(io.StringIO()):
@@ -324,41 +328,40 @@ def _rccl_world1_worker(port, q):
             agent.update_agent(_batch(tr, synth.minibatch_indices(s, n=2000, B=B, seed=7)))
             out.append((agent.policy_net.flat_grad.cpu().numpy().copy(), agent.policy_net.flat.cpu().numpy().copy(),
                         agent.target_net.flat.cpu().numpy().copy()))
-    torch.distributed.all_reduce = real
-    # every step sent the flat gradient arena itself (no staging copy) through the backend, on the device
-    assert len(calls) == STEPS and all(c == ((agent.policy_net.flat_grad.numel(),), "cuda", agent.policy_net.flat_grad.data_ptr()) for c in calls), calls
+    if forced:
+        torch.distributed.all_reduce = real
+        # every step sent the flat gradient arena itself (no staging copy) through the backend, on the device
+        assert len(calls) == STEPS and all(c == ((agent.policy_net.flat_grad.numel(),), "cuda", agent.policy_net.flat_grad.data_ptr()) for c in calls), calls
     assert agent.optimizer.grad_scale == 1.0
     q.put(out)
-    torch.distributed.barrier()
-    torch.distributed.destroy_process_group()
+    if forced:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def test_rccl_world1_three_steps_are_bit_identical_to_the_single_process_step():
     """the RCCL path had never executed, not even at world size 1.  One rank initialises `nccl`, runs three
     `update_agent` steps through parallel.data_parallel_step (all-reduce over the one rank, then clamp + Adam with scale 1) and must
-    reproduce the plain single-process steps BIT FOR BIT: gradients, parameters, Adam-driven target syncs."""
-    import io
-    import contextlib
-    s_ = socket.socket()
-    s_.bind(("127.0.0.1", 0))
-    port = s_.getsockname()[1]
-    s_.close()
+    reproduce the plain single-process steps BIT FOR BIT: gradients, parameters, target syncs."""
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_rccl_world1_worker, args=(port, q))
-    p.start()
-    got = q.get(timeout=600)
-    p.join(120)
-    assert p.exitcode == 0
-    dev = torch.device("cuda:0")
-    tr = synth.replay_transitions(n=2000, T=25, seed=2019)
-    agent = _agent(dev)
-    np.random.seed(5)
-    with contextlib.redirect_stdout(io.StringIO()):
-        for s in range(STEPS):
-            agent.update_agent(_batch(tr, synth.minibatch_indices(s, n=2000, B=B, seed=7)))
-            for x, y in zip(got[s], (agent.policy_net.flat_grad, agent.policy_net.flat, agent.target_net.flat)):
-                np.testing.assert_array_equal(x, y.cpu().numpy())
+    got = {}
+    for forced in (True, False):
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_world1_worker, args=(port, q, forced))
+        p.start()
+        got[forced] = q.get(timeout=600)
+        p.join(120)
+        assert p.exitcode == 0
+    moved = 0.0
+    for a, b in zip(got[True], got[False]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        moved = max(moved, float(np.abs(a[0]).max()))
+    assert moved > 0                                     # real gradients went through the collective
 
 
 def test_bench_force_dist_runs_the_multi_rank_branch_on_rccl():
