@@ -51,6 +51,11 @@ from ivos_w_amd import synth                # noqa: E402
 GFLOP_PER_FRAME = 10.779365376              # 5 389 682 688 MAC x 2, conv stack + fc
 CONV_LAUNCHES_PER_FRAME_CHUNK = 54           # stem + 53 tower convs, per chunk
 PEAK_BF16_TFLOPS = 2500.0                    # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# The MEASURED attainable roof of a both-operands-streamed bf16 contraction at the tower's own GEMM shapes, random data, one MI355X
+# (round 5 step A: tools/ubench/gemm_tile_bench.hip, profiles/r05_gemm_tile_bench.txt): whole layer (prologue + K loop + bf16 epilogue) and
+# K loop only, best of the tower's shapes.  The fill path of a CU (23 - 29 B/clk through its L1 from L2, ~10 from HBM) and the power-limited
+# 1.6 - 1.8 GHz under MFMA load set it, not the register tile; LDS-fed MFMA without any fill tops out at 1 660 TFLOP/s.
+ATTAINABLE_BF16_TFLOPS = {"layer": 1100.0, "k_loop": 1310.0, "lds_fed_mfma_no_fill": 1660.0}
 PEAK_F32_TFLOPS = 157.3
 BF16_SCORE_RTOL = 4e-3                      # the bf16 mode's stated tolerance (tests/test_gpu_assess.py)
 DQN_GFLOP_PER_STEP = 10.5                    # 3 forwards + backward at B=128, T=25
@@ -412,6 +417,12 @@ def bench_assess(args, rank, world, dev, dist):
             "launches_per_step": launches, "avg_launch_us": round(conv_ms * 1e3 / max(launches, 1), 2),
             "flops_per_launch": flops_step / max(launches, 1), "kernel_ms_per_step": round(conv_ms, 3),
             "streams": 2 if split else 1,
+            "attainable": ({"peak_layer": ATTAINABLE_BF16_TFLOPS["layer"], "peak_k_loop": ATTAINABLE_BF16_TFLOPS["k_loop"],
+                            "frac_of_attainable_layer": round(achieved / ATTAINABLE_BF16_TFLOPS["layer"], 4),
+                            "frac_of_attainable_k_loop": round(achieved / ATTAINABLE_BF16_TFLOPS["k_loop"], 4),
+                            "source": "measured, not estimated: a one-wave-per-SIMD 4x4-register-tile MFMA kernel with both operands by LDS-DMA on random bf16 at the "
+                                      "tower's GEMM shapes (profiles/r05_gemm_tile_bench.txt); the 8-wave layer kernels of this build reach the same"}
+                           if args.precision == "bf16" else None),
             "timing": "one HIP-event pair per forward pass around the tower's launches, inside the timed region (family time includes its own launch gaps)"
                       + ("; the batch runs as two halves on two streams: family time = latest end - earliest start of the halves' tower spans" if split else "")}
     if rank == 0 and args.precision == "bf16" and not args.no_clock_probe:

@@ -598,7 +598,11 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                     u32x2 pk;
                     pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y) & (in ? 0xffffffffu : 0u);
                     pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w) & (in ? 0xffffffffu : 0u);
-                    lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                    // swizzle key from the COLUMN of the halo raster, not from the row index (round 5): phase B's 16-lane read groups are
+                    // {x .. x+3, x+12 .. x+15} of one raster line and {x+4 .. x+11} of the next - 16 consecutive columns, so (hx & 1, hx >> 1)
+                    // puts them on 16 different 16-byte slots (the line pitch 18 is even: a row's 128-byte half is its column's parity);
+                    // with (hr >> 1) & 7 two pairs of every group shared a slot (PMC: 32 % of the kernel's LDS cycles were conflicts)
+                    lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hx >> 1) & 7)) << 4) + 8 * lhalf, pk);
                 }
             }
         }
@@ -622,43 +626,84 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
             const int q = (grp * PB + i) * 32 + lrow;
             hb[i] = (q >> 4) * HT + (q & 15);
         }
+        if constexpr (WL) {
+            // Software-pipelined form (round 5): the fragment reads of a k-step - 4 pixel tiles - are issued a WHOLE k-step ahead into the
+            // other of two register sets, and across the step boundary the next step's four weight fragments and first pixel fragments
+            // go out under the last k-step's MFMAs; the workgroup barrier of a double step sits in front of that prefetch.  (The
+            // half-step lookahead of the register-weights form left every step opening with ~10 exposed LDS reads.)
+            static_assert(!WL || (NSTEP % 2 == 0 && PB == 4), "double steps of four pixel tiles");
+            u32x4 pfb[2][PB], wcb[2][4];
+            auto rd_all = [&](int buf, int step, int ks) {
+                const int tap = step / NSL, sl = step - tap * NSL;
+                const unsigned key = (((lrow & 15) + tap % 3) >> 1) & 7;     // the raster column of every pixel tile of this lane: (q & 15) + kx
+                const unsigned x = ((2 * ks + lhalf) ^ key) << 4;
+#pragma unroll
+                for (int i = 0; i < PB; ++i) pfb[buf][i] = lds_read_b128(lds_base + sl * T1S + (hb[i] + (tap / 3) * HT + (tap % 3)) * ROWB + x);
+            };
+            auto rd_w = [&](int buf, int step) {
+                const unsigned wa = lds_base + (((step >> 1) & 1) ? WB1_OFF : WB0_OFF) + (ctw * 8 + (step & 1) * 4) * 1024 + lane * 16;
+                wcb[buf][0] = lds_read_b128_o<0>(wa); wcb[buf][1] = lds_read_b128_o<1024>(wa);
+                wcb[buf][2] = lds_read_b128_o<2048>(wa); wcb[buf][3] = lds_read_b128_o<3072>(wa);
+            };
+            // double step 0 has landed for this wave (double step 1's four pieces may be younger); the barrier publishes it
+            wait_vmcnt<4>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            rd_w(0, 0);
+            rd_all(0, 0, 0);
+#pragma unroll 1
+            for (int d = 0; d < NSTEP / 2; ++d) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int step = 2 * d + h;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        if (ks < 3) {
+                            rd_all((ks + 1) & 1, step, ks + 1);
+                            lgkm_wait<PB>();
+                        } else if (step + 1 < NSTEP) {
+                            if (h == 1) {
+                                // double step d + 1: this wave's pieces have landed (nothing younger is in flight), the barrier publishes
+                                // them and says every wave has read the last weights of double step d: its slot takes d + 2
+                                wait_vmcnt<0>();
+                                __builtin_amdgcn_s_barrier();
+                                asm volatile("" ::: "memory");
+                                if (d + 2 < NSTEP / 2) wb_issue(d + 2);
+                            }
+                            rd_w(h ^ 1, step + 1);
+                            rd_all(0, step + 1, 0);
+                            lgkm_wait<PB + 4>();
+                        } else {
+                            lgkm_wait<0>();
+                        }
+#pragma unroll
+                        for (int i = 0; i < PB; ++i) acc[i] = mfma_bf16(wcb[h][ks], pfb[ks & 1][i], acc[i]);
+                    }
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int step = 0; step < NSTEP; ++step) {   // step = tap * NSL + slice
             const int tap = step / NSL, sl = step - tap * NSL;
             u32x4 wc[4];
-            if constexpr (WL) {
-                static_assert(!WL || NSTEP % 2 == 0, "double steps");
-                if ((step & 1) == 0) {
-                    // double step d: this wave's pieces of it have landed (only d + 1's four may be younger - in the first round; later
-                    // d + 1 is issued behind this barrier), the barrier publishes it and frees the slot of d - 1 for d + 1
-                    const int d = step >> 1;
-                    if (d == 0) wait_vmcnt<4>(); else wait_vmcnt<0>();
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (d >= 1 && 2 * (d + 1) < NSTEP) wb_issue(d + 1);
-                }
-                const unsigned wa = lds_base + (((step >> 1) & 1) ? WB1_OFF : WB0_OFF) + (ctw * 8 + (step & 1) * 4) * 1024 + lane * 16;
-                wc[0] = lds_read_b128_o<0>(wa); wc[1] = lds_read_b128_o<1024>(wa); wc[2] = lds_read_b128_o<2048>(wa); wc[3] = lds_read_b128_o<3072>(wa);
-            } else {
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
-                if (step + 1 < NSTEP) {
+            for (int ks = 0; ks < 4; ++ks) wc[ks] = as_u32x4(wn[ks]);
+            if (step + 1 < NSTEP) {
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
-                }
+                for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
             }
-            unsigned rowa[PB], rkey[PB];
+            unsigned rowa[PB];
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 const int hr = hb[i] + (tap / 3) * HT + (tap % 3);
                 rowa[i] = lds_base + sl * T1S + hr * ROWB;
-                rkey[i] = (hr >> 1) & 7;
             }
+            const unsigned rkey = (((lrow & 15) + tap % 3) >> 1) & 7;    // the raster column of every pixel tile of this lane: (q & 15) + kx
             u32x4 pf[PB];
             auto rd = [&](int ks, int half) {
                 const int ch = 2 * ks + lhalf;
 #pragma unroll
-                for (int i = 0; i < HB; ++i) pf[half * HB + i] = lds_read_b128(rowa[half * HB + i] + ((ch ^ rkey[half * HB + i]) << 4));
+                for (int i = 0; i < HB; ++i) pf[half * HB + i] = lds_read_b128(rowa[half * HB + i] + ((ch ^ rkey) << 4));
             };
             rd(0, 0);
             rd(0, 1);
@@ -673,6 +718,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                 for (int i = HB; i < PB; ++i) acc[i] = mfma_bf16(wc[ks], pf[i], acc[i]);
                 if (ks < 3) rd(ks + 1, 1);
             }
+        }
         }
         __builtin_amdgcn_s_barrier();                // every wave is done reading t1: t2 takes its place
         asm volatile("" ::: "memory");
@@ -1221,7 +1267,7 @@ __global__ __launch_bounds__(512) void bneck_half16_kernel(BneckWideArgs p) {
                     u32x2 pk;
                     pk.x = relu2_bf16(acc[i][4 * g] + bq[g].x, acc[i][4 * g + 1] + bq[g].y) & (in ? 0xffffffffu : 0u);
                     pk.y = relu2_bf16(acc[i][4 * g + 2] + bq[g].z, acc[i][4 * g + 3] + bq[g].w) & (in ? 0xffffffffu : 0u);
-                    lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hr >> 1) & 7)) << 4) + 8 * lhalf, pk);
+                    lds_write_b64(lds_base + (ctw >> 1) * T1S + hr * ROWB + ((((ctw & 1) * 4 + g) ^ ((hx >> 1) & 7)) << 4) + 8 * lhalf, pk);   // column key: see bneck_halo_kernel
                 }
             }
         }
@@ -1254,18 +1300,18 @@ __global__ __launch_bounds__(512) void bneck_half16_kernel(BneckWideArgs p) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) wn[ks] = *wfrag(p.fb, ctw, KSB, (step + 1) * 4 + ks, lane);
             }
-            unsigned rowa[4], rkey[4];
+            unsigned rowa[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int hr = hb[i] + (tap / 3) * HTX + (tap % 3);
                 rowa[i] = lds_base + sl * T1S + hr * ROWB;
-                rkey[i] = (hr >> 1) & 7;
             }
+            const unsigned rkey = (((lrow & 15) + tap % 3) >> 1) & 7;    // column key (see bneck_halo_kernel)
             u32x4 pf[4];
             auto rd = [&](int ks, int half) {
                 const int ch = 2 * ks + lhalf;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(rowa[half * 2 + i] + ((ch ^ rkey[half * 2 + i]) << 4));
+                for (int i = 0; i < 2; ++i) pf[half * 2 + i] = lds_read_b128(rowa[half * 2 + i] + ((ch ^ rkey) << 4));
             };
             rd(0, 0);
             rd(0, 1);
