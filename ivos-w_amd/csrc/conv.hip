@@ -740,7 +740,18 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LW) * 64) void conv_igemm_ws_k
 // 16-KB weight tiles stream per tap.  Fill bytes per tap drop from 48 KB to ~21 KB.
 //   tile = F frames x TH x TW output pixels (256), BN = 128 output channels, 8 compute + 8 loader waves
 //   LDS: two patch buffers (channel slices alternate) | 3-slot weight ring | epilogue tile aliases everything
-template <int F, int TH>
+// Swizzle key of a patch row from its PATCH COORDINATES (round 5; it was (hr >> 1) & 7 of the linear row index: 49 % of this kernel's LDS
+// cycles were bank conflicts).  A 16-lane ds_read_b128 group reads, at one tap, TW = 16: columns {x .. x+3, x+12 .. x+15} of one patch line and
+// {x+4 .. x+11} of the next - 16 consecutive columns -> key = (hx >> 1) & 7; TW = 8: one 4-pixel half of each of four consecutive lines
+// -> key = (hy & 3, (hx >> 1) & 1).  The line pitch TW + 2 (and the frame pitch) is even, so the row's 128-byte half is the column's parity
+// and (hx & 1, key) names 16 different 16-byte slots either way.
+template <int TW>
+__device__ __forceinline__ int patch_key(int hy, int hx) {
+    static_assert(TW == 16 || TW == 8, "tile widths of the patch kernel");
+    return TW == 16 ? ((hx >> 1) & 7) : (((hy & 3) << 1) | ((hx >> 1) & 1));
+}
+
+template <int F, int TH, bool KEYXY = true>
 __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
     typedef bf16_t T;
     constexpr int TW = TH, HW2 = TW + 2, HP = (TH + 2) * HW2, HRT = F * HP;   // halo rows of the tile
@@ -792,7 +803,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
             const int hy = rem / HW2, hx = rem - hy * HW2;
             const int y = y0 - 1 + hy, x = x0 - 1 + hx;
             const bool ok = g < NG && hr < HRT && y >= 0 && y < p.H && x >= 0 && x < p.W && b0 + f < p.B;   // (frames past the batch in the last 4-frame tile read zeros)
-            abase[i] = ok ? X + (((long)(b0 + f) * p.H + y) * p.W + x) * p.Cin + (cpos ^ ((hr >> 1) & 7)) * CE : zeros;
+            abase[i] = ok ? X + (((long)(b0 + f) * p.H + y) * p.W + x) * p.Cin + (cpos ^ (KEYXY ? patch_key<TW>(hy, hx) : ((hr >> 1) & 7))) * CE : zeros;
             okmask |= ok ? (1u << i) : 0u;
         }
         const T* bsrc[2];
@@ -845,13 +856,14 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lrow = lane & 31, lhalf = lane >> 5;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    int hb[TM];                                              // patch row of this lane's output pixel at tap (0,0)
+    int hb[TM], hy0[TM], hx0[TM];                            // patch row (and line / column) of this lane's output pixel at tap (0,0)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = (wm * TM + i) * 32 + lrow;
         const int f = m / (TH * TW), rem = m - f * (TH * TW);
         const int y = rem / TW, x = rem - y * TW;
         hb[i] = f * HP + y * HW2 + x;
+        hy0[i] = y; hx0[i] = x;
     }
     int c = 0, t = 0;
     for (int j = 0; j < nj; ++j) {
@@ -865,7 +877,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
         for (int i = 0; i < TM; ++i) {
             const int hr = hb[i] + ky * HW2 + kx;
             arow[i] = a_base + hr * ROWB;
-            asw[i] = (hr >> 1) & 7;
+            asw[i] = KEYXY ? patch_key<TW>(hy0[i] + ky, hx0[i] + kx) : ((hr >> 1) & 7);
         }
         u32x4 fa[2][TM], fb[2][TN];
         auto frag_read = [&](int ks, int buf) {
@@ -963,8 +975,14 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
             if constexpr (sizeof(T) == 2) {
                 if (patch3x3_ok(a) && tune_get("PATCH3", 1)) {
                     const int g3 = ((M + 255) / 256) * (a.Cout / 128);      // H == 8: four frames per tile, the last one may be partial
-                    if (a.H == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 8>), dim3(g3), dim3(1024), 0, st, a);
-                    else hipLaunchKernelGGL((conv3x3_patch_kernel<1, 16>), dim3(g3), dim3(1024), 0, st, a);
+                    // PATCH_KEYXY = 1: swizzle key from the patch coordinates - PMC: bank-conflict share of this kernel 0.49 -> 0.013, LDS cycles
+                    // per launch halved - and yet 74.7 against 72.4 us per res5 launch on alternating runs of one box (profiles/r05_lds_conflicts.txt):
+                    // the kernel is bound by its MFMA issue at a power-limited clock, not by LDS time, so the row-index key stays the default
+                    const bool kxy = tune_get("PATCH_KEYXY", 0) != 0;
+                    if (a.H == 8 && kxy) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 8>), dim3(g3), dim3(1024), 0, st, a);
+                    else if (a.H == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 8, false>), dim3(g3), dim3(1024), 0, st, a);
+                    else if (kxy) hipLaunchKernelGGL((conv3x3_patch_kernel<1, 16>), dim3(g3), dim3(1024), 0, st, a);
+                    else hipLaunchKernelGGL((conv3x3_patch_kernel<1, 16, false>), dim3(g3), dim3(1024), 0, st, a);
                     return;
                 }
             }
