@@ -510,6 +510,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                             r.x = bufs[bb - 1] + (size_t)lo * fe; r.y = bufs[bb] + (size_t)lo * fe;
                             r.B = hi - lo;
                             r.rev = next_dir();
+                            if (IVOSW_ABLATION && bb == 3 && tune_get("YS2ABL", 0)) r.debug |= 16;      // ablation: the stage's last block writes even pixels only
                             launch_bneck_wide(r, st);
                         }
                     }
@@ -533,6 +534,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                         r.fa = base + bq.f1_off; r.ba = reinterpret_cast<const float*>(base + d1.b_off);
                         r.fb = base + bq.f2_off; r.bb = reinterpret_cast<const float*>(base + d2.b_off);
                         r.fc = base + bq.f3_off; r.bc = reinterpret_cast<const float*>(base + d3.b_off);
+                        if (IVOSW_ABLATION && s == 2 && bb == nblk[s] - 1 && tune_get("YS2ABL", 0)) r.debug |= 16;
                         xi = yi;
                     }
                     launch_bneck_wide_stage(sa, st);

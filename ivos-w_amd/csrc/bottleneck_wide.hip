@@ -366,6 +366,9 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         pk[k] = relu2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u));
+                    // ablation (IVOSW_ABLATION builds, tunable YS2ABL): the stage's LAST block keeps only the even pixels of y - what a forwarded
+                    // conv1 + a stride-2 reader would need (how much clock do the written bytes cost?)
+                    if (ABL(p.debug, 16) && ((((i * 32 + pr) / HW) | (i * 32 + pr)) & 1)) continue;
                     *reinterpret_cast<uint4*>(Y + (size_t)(i * 32 + pr) * CIN + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
                 if (item < NACC - 1) { rr[0] = rn[0]; rr[1] = rn[1]; }
@@ -827,6 +830,7 @@ __global__ __launch_bounds__(512) void bneck_halo_kernel(BneckWideArgs p) {
                     for (int k = 0; k < 4; ++k)
                         pk[k] = relu2_bf16(v[2 * k] + __uint_as_float(w4[k] << 16), v[2 * k + 1] + __uint_as_float(w4[k] & 0xffff0000u));
                     if ((HALO_ABL & 2) && pk[0] != 0x12345678u) continue;
+                    if (ABL(p.debug, 16) && ((((i * 32 + pr) >> 4) | (i * 32 + pr)) & 1)) continue;      // ablation YS2ABL: even pixels only (see bneck_wide_body)
                     *reinterpret_cast<uint4*>(Y + pix(i * 32 + pr) + cofs) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
                 if (i < 7) { rr[0] = rn[0]; rr[1] = rn[1]; }
@@ -2141,7 +2145,7 @@ static bool bneck_half16_wanted(const BneckWideArgs& a) {
 
 void launch_bneck_wide(const BneckWideArgs& a_in, hipStream_t st) {
     BneckWideArgs a = a_in;
-    a.debug = tune_get("BDBG", 0);
+    a.debug = tune_get("BDBG", 0) | (a_in.debug & 16);
     ConvArgs d{};
     d.B = a.B; d.H = a.H; d.W = a.W; d.Ho = a.H; d.Wo = a.W; d.Cin = a.Cin; d.Cout = 4 * a.Cmid; d.KH = 0; d.stride = 1; d.res = a.ds ? nullptr : a.x;
     void* tok = prof_begin(d, 2, st);
