@@ -22,4 +22,24 @@ for k in sorted(agg):
     print(k[:120])
     for c, (n, v) in sorted(agg[k].items()):
         print(f"    {c:34s} calls {n:4d}  per call {v / n:18.1f}")
+print("""
+# ---- derived shares (per kernel and launch; GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the launch = GUI / 8; 256 CUs x 4 SIMDs;
+# SQ_* wave counters in quad-cycles).  mfma = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs); issue / wait_pipe = SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY over
+# SQ_WAVE_CYCLES, parked = the rest (s_waitcnt / s_barrier); lds = SQ_LDS_IDX_ACTIVE / (cycles x 256 CUs); conflict = share of the LDS cycles that are
+# bank-conflict cycles; tcp = texture-cache accesses per CU-cycle (one 64-byte access per clock and CU at most).  rocprofv3 --pmc SERIALISES the dispatches:
+# every launch here has the chip to itself, so a 128-workgroup launch (res4 chain: one frame per workgroup) shows half the share its CUs reach in the
+# two-stream forward, where the other half's launch fills the remaining CUs.
+# kernel                                                                 calls    Mcyc   mfma  issue wait_pipe  parked    lds conflict    tcp""")
+def per(k, c):
+    n, v = agg[k].get(c, [0, 0.0])
+    return v / n if n else 0.0
+for k in sorted(agg, key=lambda k: -per(k, "GRBM_GUI_ACTIVE") * agg[k].get("GRBM_GUI_ACTIVE", [0, 0])[0]):
+    if not any(x in k for x in fam) or per(k, "GRBM_GUI_ACTIVE") == 0:
+        continue
+    cyc = per(k, "GRBM_GUI_ACTIVE") / 8.0
+    wc = per(k, "SQ_WAVE_CYCLES") or 1.0
+    issue, waitp = per(k, "SQ_ACTIVE_INST_ANY") / wc, per(k, "SQ_WAIT_INST_ANY") / wc
+    lds = per(k, "SQ_LDS_IDX_ACTIVE")
+    print(f"# {k[:70]:70s} {agg[k]['GRBM_GUI_ACTIVE'][0]:5d} {cyc / 1e6:7.3f} {per(k, 'SQ_VALU_MFMA_BUSY_CYCLES') / (cyc * 1024):6.3f} {issue:6.3f} {waitp:9.3f} "
+          f"{max(0.0, 1 - issue - waitp):7.3f} {lds / (cyc * 256):6.3f} {(per(k, 'SQ_LDS_BANK_CONFLICT') / lds if lds else 0):8.3f} {per(k, 'TCP_TOTAL_CACHE_ACCESSES_sum') / (cyc * 256):6.3f}")
 PY
