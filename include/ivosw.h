@@ -284,6 +284,15 @@ int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, const float* 
  * is the shader clock the chip ran at under that load.                                                                       */
 int ivosw_clock_probe(unsigned long long* out2, int spin_us, ivosw_stream_t stream);
 
+/* Tuning probe (round 5): the one-wave-per-SIMD, 4 x 4-register-tile contraction of the attainable-roof measurement
+ * (csrc/gemm_bt.h; tools/ubench/gemm_tile_bench.hip times it): C [M][N] bf16 = act(A [M][K] . B [N][K]^T + bias [N]),
+ * both operands K-major bf16, fp32 accumulation, act = ReLU when relu != 0.  M % 256 == 0, N % 256 == 0, K % 32 == 0, K >= 32.
+ * No reference function stands behind it: the tower's 1x1 convolutions (models/assessment.py:58-61 through torchvision's
+ * Bottleneck) are contractions of exactly this form, and the product path runs them in the 8-wave kernels that reach the same rate.
+ * ts [M/256 * N/256][4] uint64 (may be NULL): s_memtime at start / after the K loop / at the end, s_memrealtime span.             */
+int ivosw_gemm_bt_probe(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int relu,
+                        unsigned long long* ts, ivosw_stream_t stream);
+
 /* Tuning probe: ONE launch of the res2 stage kernel (the three bottlenecks of res2 + res3's forwarded conv1; reference
  * models/assessment.py:58-59) on x [B,64,64,64] bf16 with the weights of a packed bf16 arena (ivosw_assess_pack); y [B,64,64,256]
  * (y_s2 != 0: the even pixels, [B,32,32,256]), t1out [B,64,64,128]; ts [B*32][16] uint64 phase stamps or NULL.            */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ivosw_bneck_probe": (_i, [_p] * 11 + [_i] * 5 + [_p, _p]),
     "ivosw_bneck_wide_probe": (_i, [_p] * 9 + [_i] * 5 + [_p, _p]),
     "ivosw_res2_stage_probe": (_i, [_p] * 4 + [_i] * 2 + [_p, _p]),
+    "ivosw_gemm_bt_probe": (_i, [_p] * 4 + [_i] * 4 + [_p, _p]),
     "ivosw_clock_probe": (_i, [_p, _i, _p]),
 }
 

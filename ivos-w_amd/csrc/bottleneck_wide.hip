@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "conv.h"
+#include "gemm_bt.h"
 #include "mfma_tile.h"
 
 namespace ivosw {
@@ -2207,6 +2208,23 @@ extern "C" int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, co
     a.zeros = f + 2 * n1 + n2;                      // the caller provides 256 zeroed bytes behind the three weight copies
     IVOSW_REQUIRE(bneck_wide_fusable(a), "shape is not covered by the wide fused bottleneck kernel");
     launch_bneck_wide(a, st);
+    IVOSW_CHECK_LAUNCH();
+    return IVOSW_OK;
+}
+
+// Tuning probe: the big-register-tile contraction of round 5's attainable-roof measurement (gemm_bt.h) behind the C ABI, so that the
+// kernel the micro-benchmark times is also built into the library and checked by the GPU tests.
+extern "C" int ivosw_gemm_bt_probe(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int relu,
+                                   unsigned long long* ts, ivosw_stream_t stream) {
+    using namespace ivosw;
+    IVOSW_REQUIRE(A && B && bias && C, "null pointer");
+    IVOSW_REQUIRE(M > 0 && N > 0 && K >= 32 && M % 256 == 0 && N % 256 == 0 && K % 32 == 0, "M % 256, N % 256, K % 32 must be 0");
+    IVOSW_REQUIRE((long)256 * K * 2 < (1L << 31), "K too large for 32-bit tile offsets");
+    IVOSW_ON_DEVICE_OF(C);
+    BtArgs a{};
+    a.A = static_cast<const bf16_t*>(A); a.B = static_cast<const bf16_t*>(B); a.bias = bias; a.C = static_cast<bf16_t*>(C);
+    a.M = M; a.N = N; a.K = K; a.relu = relu; a.ts = ts;
+    hipLaunchKernelGGL(gemm_bt_kernel<0>, dim3((M / 256) * (N / 256)), dim3(256), 0, as_stream(stream), a);
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }

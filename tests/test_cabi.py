@@ -159,6 +159,9 @@ def test_shipped_kernels_scratch_budget():
             over[name] = (r["spill"], cap)
         assert r["lds"] <= 163840 and r["vgpr"] <= 512
     assert not over, over
+    # the one-wave-per-SIMD contraction (gemm_bt.h) really keeps its 4 x 4 accumulator tiles in the AGPR half of the file
+    bt = [r for n, r in table.items() if "gemm_bt_kernel" in n]
+    assert bt and all(r["agpr"] == 256 and r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 131072 for r in bt), bt
     # the default-path kernels this round touched: spill-free
     for key in ("bneck_halo_kernelILi128ELb1", "bneck_halo_kernelILi128ELb0", "conv1x1_wide_kernel"):
         hits = [r for n, r in table.items() if key in n]

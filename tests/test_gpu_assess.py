@@ -742,3 +742,41 @@ def test_forward_refuses_an_arena_packed_for_another_dtype(dev):
                                       L.stream_ptr(dev))
         assert rc != 0 and b"packed for another dtype" in lib.ivosw_last_error()
     assert torch.equal(net(ttf, ttp), want)                 # the right dtype still runs
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(256, 256, 32, 1), (512, 256, 96, 0), (1024, 512, 768, 1), (256, 768, 160, 1)])
+def test_big_register_tile_contraction_vs_torch(dev, M, N, K, relu):
+    """csrc/gemm_bt.h (round 5: one wave per SIMD, 4 x 4 MFMA tiles in 256 AGPRs, both operands by LDS-DMA; the kernel of the attainable-roof
+    measurement) through the C ABI against torch's fp32 contraction of the same bf16 operands: K = 32 .. 160 exercises the ring's
+    out-of-range phantom tiles (fewer K-tiles than the 3.5 the ring runs ahead), 768 the steady state; asymmetric operands catch a transposed
+    or mis-tiled store."""
+    from ivos_w_amd import _lib as L
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * (1 + torch.arange(M)[:, None] % 7 * 0.25)).to(torch.bfloat16).to(dev)
+    B = (torch.randn(N, K, generator=g) / K ** 0.5 * (1 + torch.arange(N)[:, None] % 5 * 0.5)).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.check(L.lib().ivosw_gemm_bt_probe(L.dptr(A), L.dptr(B), L.dptr(bias), L.dptr(C), M, N, K, relu, None, L.stream_ptr(dev)), "gemm_bt_probe")
+    want = A.float() @ B.float().t() + bias
+    if relu:
+        want = torch.relu(want)
+    got = C.float()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs() / (want.abs() + 1.0)
+    assert float(err.max()) < 6e-3, float(err.max())          # one bf16 rounding of the output (2^-8) on top of fp32 accumulation
+
+
+def test_patch_kernel_coordinate_swizzle_is_bit_identical(dev, net16):
+    """conv3x3_patch_kernel with the swizzle key taken from the patch coordinates (PATCH_KEYXY=1: bank-conflict share 0.49 -> 0.013 by PMC,
+    3 % slower, therefore off by default) moves the same values through a different LDS placement: res5 and the scores are bit-identical."""
+    from ivos_w_amd import _lib as L
+    _, _, ttf, ttp = inputs(dev, 5, True)
+    got = {}
+    try:
+        for mode in (1, 0):
+            L.tune_set(b"PATCH_KEYXY", mode)
+            got[mode] = [net16.forward_tap(ttf, ttp, "res5")[1].clone(), net16(ttf, ttp).clone()]
+    finally:
+        L.tune_set(b"PATCH_KEYXY", 0)
+    for a, b in zip(got[1], got[0]):
+        assert torch.equal(a, b)
