@@ -757,7 +757,9 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
     constexpr int TW = TH, HW2 = TW + 2, HP = (TH + 2) * HW2, HRT = F * HP;   // halo rows of the tile
     constexpr int NG = (HRT + 7) / 8;                                          // 1-KB DMA row groups per patch
     constexpr int PB = NG * 1024;
-    constexpr int NW = 8, LW = 8, TM = 2, TN = 2, BM = 256, BN = 128, KE = 64, CE = 8;
+    constexpr int BM = F * TH * TW, TM = BM / 128;           // 256 pixels per tile (TM = 2), or 128 (F = 2 frames of 8 x 8: small launches, round 5)
+    constexpr int NW = 8, LW = 8, TN = 2, BN = 128, KE = 64, CE = 8;
+    static_assert(BM == 256 || BM == 128, "a tile is 8 or 4 pixel tiles of 32");
     constexpr int WSLOT = BN * ROWB, WR = 3;
     constexpr int W_OFF = 2 * PB;
     constexpr int EPI_BYTES = BM * BN * 4;
@@ -979,6 +981,15 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
                     // per launch halved - and yet 74.7 against 72.4 us per res5 launch on alternating runs of one box (profiles/r05_lds_conflicts.txt):
                     // the kernel is bound by its MFMA issue at a power-limited clock, not by LDS time, so the row-index key stays the default
                     const bool kxy = tune_get("PATCH_KEYXY", 0) != 0;
+                    // evaluation-size launches (round 5): fewer 4-frame tiles than PATCH_SMALL workgroups (res5 at < 128 frames per launch:
+                    // 13 x 4 = 52 workgroups for 50 frames) -> 2-frame tiles, twice the workgroups; same (slice, tap) K order per output
+                    // element, so a frame's result does not depend on which of the two ran (kernel trace at 100 units: this layer took
+                    // 4.4 x its per-frame time at batch 256)
+                    if (a.H == 8 && !kxy && g3 < tune_get("PATCH_SMALL", 128)) {
+                        const int g2 = ((M + 127) / 128) * (a.Cout / 128);
+                        hipLaunchKernelGGL((conv3x3_patch_kernel<2, 8, false>), dim3(g2), dim3(1024), 0, st, a);
+                        return;
+                    }
                     if (a.H == 8 && kxy) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 8>), dim3(g3), dim3(1024), 0, st, a);
                     else if (a.H == 8) hipLaunchKernelGGL((conv3x3_patch_kernel<4, 8, false>), dim3(g3), dim3(1024), 0, st, a);
                     else if (kxy) hipLaunchKernelGGL((conv3x3_patch_kernel<1, 16>), dim3(g3), dim3(1024), 0, st, a);

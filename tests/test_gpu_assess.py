@@ -780,3 +780,39 @@ def test_patch_kernel_coordinate_swizzle_is_bit_identical(dev, net16):
         L.tune_set(b"PATCH_KEYXY", 0)
     for a, b in zip(got[1], got[0]):
         assert torch.equal(a, b)
+
+
+def test_small_launch_patch_tiles_are_bit_identical(dev, net16):
+    """Evaluation-size launches run res5's 3x3 on 2-frame tiles (conv3x3_patch_kernel<2, 8>: twice the workgroups) instead of 4-frame tiles
+    (PATCH_SMALL=0 forces those): the same (slice, tap) K order per output element, so res5 and the scores agree bit for bit - odd frame counts
+    (a partial last tile in either tiling) included."""
+    from ivos_w_amd import _lib as L
+    for B in (8, 5, 3):
+        _, _, ttf, ttp = inputs(dev, B, B == 8)
+        got = {}
+        try:
+            for mode in (0, 128):
+                L.tune_set(b"PATCH_SMALL", mode)
+                got[mode] = [net16.forward_tap(ttf, ttp, "res5")[1].clone(), net16(ttf, ttp).clone()]
+        finally:
+            L.tune_set(b"PATCH_SMALL", 128)
+        for a, b in zip(got[128], got[0]):
+            assert torch.equal(a, b), B
+
+
+def test_small_launch_wide_1x1_tiles_are_bit_identical(dev, net16):
+    """The K-heavy 1x1 layers on 128-pixel tiles (conv1x1_wide_kernel<4>, two workgroups per CU; tunable WIDE_SMALL, off by default: measured inside
+    the noise at evaluation sizes) against the 256-pixel tiles: same K order per output element - res4, res5 and the scores agree bit for bit, odd
+    frame counts included."""
+    from ivos_w_amd import _lib as L
+    for B in (8, 5, 3):
+        _, _, ttf, ttp = inputs(dev, B, B == 8)
+        got = {}
+        try:
+            for mode in (0, 160):
+                L.tune_set(b"WIDE_SMALL", mode)
+                got[mode] = [net16.forward_tap(ttf, ttp, "res4")[1].clone(), net16.forward_tap(ttf, ttp, "res5")[1].clone(), net16(ttf, ttp).clone()]
+        finally:
+            L.tune_set(b"WIDE_SMALL", 0)
+        for a, b in zip(got[160], got[0]):
+            assert torch.equal(a, b), B
