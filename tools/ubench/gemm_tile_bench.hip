@@ -73,9 +73,19 @@ static int check(const BtArgs& a, const std::vector<uint16_t>& A, const std::vec
     return bad;
 }
 
+static inline float grand() {        // ~ N(0, 1): sum of 12 uniforms
+    float s = 0.f;
+    for (int i = 0; i < 12; ++i) s += (rnd() >> 8) * (1.0f / 16777216.0f);
+    return s - 6.0f;
+}
+
 int main(int argc, char** argv) {
     const int shapes[][3] = {{65536, 1024, 768}, {65536, 256, 2304}, {262144, 512, 128}, {65536, 256, 1024}, {16384, 2048, 1536}, {8192, 8192, 8192}};
     const int nshape = argc > 1 ? atoi(argv[1]) : 6;
+    // data: 0 = uniform [-1, 1) (the worst case for switching power, the guide's convention), 1 = what the tower feeds its contractions:
+    // A = ReLU of a gaussian (half zeros, the rest positive: a post-ReLU bf16 activation), B = gaussian weights
+    const int data = argc > 2 ? atoi(argv[2]) : 0;
+    printf("data: %s\n", data ? "A = relu(gaussian), B = gaussian / sqrt(K)  (tower-like)" : "A, B uniform [-1, 1)  (random)");
     int bad = 0;
     for (int si = 0; si < nshape && si < 6; ++si) {
         const int M = shapes[si][0], N = shapes[si][1], K = shapes[si][2];
@@ -83,8 +93,13 @@ int main(int argc, char** argv) {
         std::vector<uint16_t> A((size_t)M * K), B((size_t)N * K);
         std::vector<float> bias(N);
         const float sc = 1.0f;
-        for (auto& v : A) v = f2bf(urand() * sc);
-        for (auto& v : B) v = f2bf(urand() * (4.0f / sqrtf((float)K)));
+        if (data) {
+            for (auto& v : A) { const float g = grand(); v = f2bf(g > 0.f ? g : 0.f); }
+            for (auto& v : B) v = f2bf(grand() * (1.4f / sqrtf((float)K)));
+        } else {
+            for (auto& v : A) v = f2bf(urand() * sc);
+            for (auto& v : B) v = f2bf(urand() * (4.0f / sqrtf((float)K)));
+        }
         for (auto& v : bias) v = urand();
         BtArgs a{};
         void *dA, *dB, *dC, *dbias, *dts;
