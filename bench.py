@@ -28,6 +28,11 @@ are outside the pair), so family time <= ms_per_step by construction and nothing
 re-run in two child processes under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (live_traffic(); counters only, ~10 s); if
 rocprofv3 is missing or a child fails, the committed summary of the same passes (profiles/pmc_traffic_latest.json) is quoted and
 `traffic_source` says so.
+`roofline.attainable` (round 5): the MEASURED roof of a both-operands-streamed bf16 contraction at the tower's GEMM shapes on this chip
+(tools/ubench/gemm_tile_bench.hip, profiles/r05_gemm_tile_bench.txt: 1.1 PFLOP/s per layer, 1.31 in the K loop) and the achieved rate as a
+fraction of it, beside `frac` against the 2.5 PFLOP/s peak.
+`dqn.dp_critical_path` (round 5, N = 1): the DQN step re-run in a child through the N > 1 branch on nccl with ONE rank (`--gpus 1 --force-dist`:
+process group, all-reduce of the gradient arena in every step, clamp + Adam with 1/world) against the fused single-GPU step.
 `checked`: after the timed region a sample of the B=256 scores is compared with the oracle on the CPU (and the fp32 parity
 mode, which is also timed: `fp32`); the line is not printed if they disagree.  cpu_baseline: torch-CPU restatements of the
 reference path (kind "port") on bounded samples, rank 0, N=1 only.
