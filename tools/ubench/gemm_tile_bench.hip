@@ -129,6 +129,28 @@ int main(int argc, char** argv) {
         run<8 | 32>("no epilogue, DMA re-reads 1 KiB", a, (unsigned long long*)dts, reps);
         run<8 | 2 | 32>("no epi, no frag reads, DMA 1 KiB", a, (unsigned long long*)dts, reps);
         run<0>("full (again)", a, (unsigned long long*)dts, reps);
+        if (K >= 128) {           // the persistent form: one workgroup per CU, the ring runs across tile boundaries
+            const int grid = (M / 256) * (N / 256), G = grid < 256 ? grid : 256;
+            BtArgs b = a; b.ts = nullptr;
+            CK(hipMemset(dC, 0xff, (size_t)M * N * 2));
+            hipLaunchKernelGGL(gemm_bt_persist_kernel<0>, dim3(G), dim3(256), 0, 0, b);
+            CK(hipDeviceSynchronize());
+            bad += check(a, A, B, bias);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEvent_t e0, e1;
+                CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_bt_persist_kernel<0>, dim3(G), dim3(256), 0, 0, b);
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_bt_persist_kernel<0>, dim3(G), dim3(256), 0, 0, b);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const float us = ms * 1000.f / reps;
+                printf("  %-34s %8.1f us  %7.1f TFLOP/s  (%d workgroups, %d tiles each)\n", "PERSISTENT, ring across tiles", us, 2.0 * M * N * K / us * 1e-6, G, grid / G);
+                run<0>("one tile per workgroup (again)", a, (unsigned long long*)dts, reps);
+            }
+        }
         hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias); hipFree(dts);
     }
     printf(bad ? "FAILED\n" : "ALL CHECKS PASSED\n");
