@@ -36,6 +36,7 @@ struct Plan {
     std::vector<ConvPlan> convs;
     std::vector<BlockPlan> blocks;
     size_t norm_off, zero_off, fcw_off, fcb_off, stem_w_off, stem_b_off, total;
+    size_t chain_off = 0;           // bf16: res2's weight-fragment stream for res2_chain_kernel (0 = none)
     int t_stem_w3, t_stem_w1, t_stem_bn, t_fcw, t_fcb, t_mean, t_std;
 };
 
@@ -96,6 +97,7 @@ static Plan make_plan(int dtype) {
             inpl = planes[s] * 4;
         }
     P.t_fcw = t; P.t_fcb = t + 1;
+    if (dtype == IVOSW_BF16) P.chain_off = take(res2_chain_stream_bytes());
     P.total = align_up(off, 256);
     return P;
 }
@@ -241,6 +243,16 @@ extern "C" int ivosw_assess_pack(void* packed, int dtype, const void* const* ten
                             reinterpret_cast<float*>(base + bp.cat_b_off), st);
             if (bp.cat_fw_off) launch_fragpack(base + bp.cat_w_off, c3.Cout, c3.Cin + cd.Cin, base + bp.cat_fw_off, st);
         }
+    if (P.chain_off) {
+        Res2ChainPackArgs q{};
+        auto W = [&](int ci) { return reinterpret_cast<const bf16_t*>(base + P.convs[ci].w_off); };
+        auto Bi = [&](int ci) { return reinterpret_cast<const float*>(base + P.convs[ci].b_off); };
+        for (int b = 0; b < 4; ++b) { q.w1[b] = W(P.blocks[b].c1); q.b1[b] = Bi(P.blocks[b].c1); }
+        for (int b = 0; b < 3; ++b) { q.w2[b] = W(P.blocks[b].c2); q.b2[b] = Bi(P.blocks[b].c2); q.w3[b] = W(P.blocks[b].c3); q.b3[b] = Bi(P.blocks[b].c3); }
+        q.wd = W(P.blocks[0].ds); q.bd = Bi(P.blocks[0].ds);
+        q.out = base + P.chain_off;
+        launch_res2_chain_pack(q, st);
+    }
     if (dtype == IVOSW_F32X3) {
         // the three-pass mode reads pre-split weights (conv.hip: ktile_mma_x3): every conv's K-major array and the concatenated
         // [conv3 | downsample] arrays, in place, AFTER everything that read them as fp32 (the concatenation above)
@@ -442,6 +454,16 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     auto run_stage = [&](int s, const char* x_in, int nb, char* out, int foff) {
         const char* x = x_in;
         int hw = hw_in[s];
+        if (s == 0 && stage2 && P.chain_off && tune_get("RES2_CHAIN", 1)) {
+            // round 6: the register-chained form of the stage kernel (res2_chain.hip); RES2_CHAIN=0 is the round-3 stage kernel
+            Res2ChainArgs q{};
+            q.x = x; q.y = out; q.t1out = bf.m1 + (size_t)foff * 64 * 64 * 128 * es;
+            q.wstream = base + P.chain_off; q.zeros = base + P.zero_off;
+            q.B = nb; q.y_s2 = ys2 ? 1 : 0;
+            q.rev = next_dir();
+            launch_res2_chain(q, st);
+            return;
+        }
         if (s == 0 && stage2) {
             Res2StageArgs q = res2_stage_args(P, base);
             q.x = x; q.y = out; q.t1out = bf.m1 + (size_t)foff * 64 * 64 * 128 * es;
@@ -667,6 +689,15 @@ extern "C" int ivosw_res2_stage_probe(const void* packed, const void* x, void* y
                                       ivosw_stream_t stream) {
     IVOSW_REQUIRE(packed && x && y && t1out && B > 0, "null pointer");
     IVOSW_ON_DEVICE_OF(y);
+    if (tune_get("RES2_CHAIN", 1) && plan_for(IVOSW_BF16).chain_off && !ts) {
+        const Plan& P = plan_for(IVOSW_BF16);
+        Res2ChainArgs c{};
+        c.x = x; c.y = y; c.t1out = t1out; c.wstream = static_cast<const char*>(packed) + P.chain_off; c.zeros = static_cast<const char*>(packed) + P.zero_off;
+        c.B = B; c.y_s2 = y_s2;
+        launch_res2_chain(c, as_stream(stream));
+        IVOSW_CHECK_LAUNCH();
+        return IVOSW_OK;
+    }
     Res2StageArgs q = res2_stage_args(plan_for(IVOSW_BF16), static_cast<const char*>(packed));
     q.x = x; q.y = y; q.t1out = t1out; q.B = B; q.y_s2 = y_s2; q.ts = ts;
     q.debug = tune_get("R2DBG", 0);

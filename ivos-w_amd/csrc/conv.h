@@ -117,6 +117,26 @@ struct Res2StageArgs {
 };
 bool res2_stage_ok(const Res2StageArgs& a);
 void launch_res2_stage(const Res2StageArgs& a, hipStream_t st);
+// the same stage with the pointwise chains kept in registers and every weight through one LDS ring (res2_chain.hip, round 6)
+struct Res2ChainArgs {
+    const void* x;                     // NHWC [B,64,64,64]: the pooled stem output
+    void* y;                           // y2: NHWC [B,64,64,256], or (y_s2) its even pixels, compactly [B,32,32,256]
+    void* t1out;                       // NHWC [B,64,64,128]: res3's first 1x1 (+ BN + ReLU) applied to y2
+    const void* wstream;               // the tile's 528 weight fragments in consumption order (launch_res2_chain_pack)
+    const void* zeros;                 // >= 256 B of device zeros
+    int B, y_s2, rev;
+};
+struct Res2ChainPackArgs {             // K-major bf16 weights (BN folded) and fp32 biases of the packed arena
+    const bf16_t* w1[4]; const float* b1[4];   // conv1 of res2's three blocks and of res3's first block ([64][64], [64][256] x 2, [128][256])
+    const bf16_t* w2[3]; const float* b2[3];   // 3x3 [64][9 * 64]
+    const bf16_t* w3[3]; const float* b3[3];   // conv3 [256][64]
+    const bf16_t* wd; const float* bd;         // block 0's downsample [256][64]
+    void* out;
+};
+size_t res2_chain_stream_bytes();
+void launch_res2_chain_pack(const Res2ChainPackArgs& a, hipStream_t st);
+bool res2_chain_ok(const Res2ChainArgs& a);
+void launch_res2_chain(const Res2ChainArgs& a, hipStream_t st);
 bool bneck_stage_fusable(const BneckWideArgs& a);
 void launch_bneck_wide_stage(const BneckStageArgs& s, hipStream_t st);
 bool bneck_wide_fusable(const BneckWideArgs& a);

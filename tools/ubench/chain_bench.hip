@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 auto fill = [&](auto kc) {
                     constexpr int K = decltype(kc)::value;
                     if constexpr (M == 0) {
-                        if constexpr (K < 8) epi_t2(std::integral_constant<int, (K >> 1) & 1>{}, std::integral_constant<int, K >> 2>{}, std::integral_constant<int, K & 1>{});
-                    } else if constexpr (K >= 2 && K < 6) epi_y(MP{}, std::integral_constant<int, (K - 2) >> 1>{}, std::integral_constant<int, (K - 2) & 1>{});
+                        if constexpr (K < 8) epi_t2(std::integral_constant<int, (K >> 1) & 1>{}, std::integral_constant<int, (K >> 2)>{}, std::integral_constant<int, K & 1>{});
+                    } else if constexpr (K >= 2 && K < 6) epi_y(MP{}, std::integral_constant<int, ((K - 2) >> 1)>{}, std::integral_constant<int, (K - 2) & 1>{});
                 };
                 lgkm<4>();                                   // this tile's bias fragment has landed (its four weight fragments may not)
                 a3[cb][0] = mm<ABL>(c[cb][0], ones, z); fill(I0{}); pin();
