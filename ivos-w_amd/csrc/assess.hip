@@ -689,11 +689,11 @@ extern "C" int ivosw_res2_stage_probe(const void* packed, const void* x, void* y
                                       ivosw_stream_t stream) {
     IVOSW_REQUIRE(packed && x && y && t1out && B > 0, "null pointer");
     IVOSW_ON_DEVICE_OF(y);
-    if (tune_get("RES2_CHAIN", 1) && plan_for(IVOSW_BF16).chain_off && !ts) {
+    if (tune_get("RES2_CHAIN", 1) && plan_for(IVOSW_BF16).chain_off) {      // ts: [B * 32][8] stamps (res2_chain.hip) instead of [B * 32][16]
         const Plan& P = plan_for(IVOSW_BF16);
         Res2ChainArgs c{};
         c.x = x; c.y = y; c.t1out = t1out; c.wstream = static_cast<const char*>(packed) + P.chain_off; c.zeros = static_cast<const char*>(packed) + P.zero_off;
-        c.B = B; c.y_s2 = y_s2;
+        c.B = B; c.y_s2 = y_s2; c.ts = ts;
         launch_res2_chain(c, as_stream(stream));
         IVOSW_CHECK_LAUNCH();
         return IVOSW_OK;

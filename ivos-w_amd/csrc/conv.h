@@ -125,6 +125,7 @@ struct Res2ChainArgs {
     const void* wstream;               // the tile's 528 weight fragments in consumption order (launch_res2_chain_pack)
     const void* zeros;                 // >= 256 B of device zeros
     int B, y_s2, rev;
+    unsigned long long* ts;            // optional [grid][8] s_memtime stamps: start, first group landed, A0, block 0, block 1, block 2, end
 };
 struct Res2ChainPackArgs {             // K-major bf16 weights (BN folded) and fp32 biases of the packed arena
     const bf16_t* w1[4]; const float* b1[4];   // conv1 of res2's three blocks and of res3's first block ([64][64], [64][256] x 2, [128][256])

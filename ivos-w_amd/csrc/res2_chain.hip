@@ -15,18 +15,19 @@
 //   * The residual is TWO MFMAs per tile against identity fragments (y, packed, is a B operand already); a bias is ONE MFMA per channel
 //     tile against a (hi, lo) bf16 split of the fp32 value (shared by a wave's two pixel tiles through the C operand).  A tile's epilogue is
 //     8 v_cvt_pk_bf16_f32 + 8 v_pk_max_i16.  Block 0 has no identity: its conv3 is [conv3 | downsample] along K (K = 128, fp32 sum as in
-//     the reference), the second half reading p from a slot-ordered LDS copy.  Summation orders differ from res2_stage.hip: this kernel is
+//     the reference), the second half on p fragments every wave takes out of the halo raster at the end of A0 (32 registers through block 0's 3x3).  Summation orders differ from res2_stage.hip: this kernel is
 //     NOT bit-identical to it; tests compare the two at the bf16 tolerance.
 //   * Only the 3x3 inputs go through LDS (padded 144-byte raster rows as in res2_stage.hip).
 //   * EVERY weight fragment (1 KB: lane l = row l & 31, k = 8 (l >> 5) ..) comes through ONE LDS ring per workgroup.  The fragments of a
 //     tile - 520, packed in consumption order by res2_chain_pack_kernel - are fetched by LDS-DMA in groups of 8 (two pieces per wave), four
-//     groups ahead of the group being opened; one s_barrier per group, s_waitcnt vmcnt(6): never drained.  (res2_stage.hip streams 1.1 MB of
+//     groups ahead of the group being opened (ring of 6 groups; 8 measured the same); one s_barrier per group, counted s_waitcnt vmcnt: never drained inside a tile.  (res2_stage.hip streams 1.1 MB of
 //     fragments per tile into registers through the texture path, every fragment once per wave that needs it; here 520 KB enter the CU once.)
 // Micro-benchmark of the block body behind the go decision: tools/ubench/chain_bench.hip, profiles/r06_chain_bench.txt.
 //
-// LDS (163 648 B): ring [0, 49152) | P (14 x 22 x 128 B, A0 only) / T1_1 (12 x 20 x 144 B) [49152, 88576) | T1_0 (14 x 22 x 144 B) / T1_2
-// (10 x 18 x 144 B) [88576, 132928) | PD (240 x 128 B, block 0) [132928, 163648).
+// LDS (132 928 B): ring [0, 49152) | P (14 x 22 x 128 B, A0 only) / T1_1 (12 x 20 x 144 B) [49152, 88576) | T1_0 (14 x 22 x 144 B) / T1_2
+// (10 x 18 x 144 B) [88576, 132928).
 // Build: this file is compiled with -mllvm -amdgpu-mfma-vgpr-form (build.py): accumulators in VGPRs, no v_accvgpr_read in the epilogues.
+#include <algorithm>
 #include <type_traits>
 
 #include "conv.h"
@@ -35,12 +36,14 @@
 namespace ivosw {
 
 namespace {
-constexpr int RC_GROUPS = 6, RC_GB = 8192, RC_RING = RC_GROUPS * RC_GB;
+#ifndef RC_GROUPS_N
+#define RC_GROUPS_N 6
+#endif
+constexpr int RC_GROUPS = RC_GROUPS_N, RC_LEAD = RC_GROUPS - 2, RC_GB = 8192, RC_RING = RC_GROUPS * RC_GB;   // a group is requested RC_LEAD groups ahead
 constexpr int RC_T1R = 144;
 constexpr int RC_P_OFF = RC_RING, RC_T1B_OFF = RC_RING;                   // P | T1_1
 constexpr int RC_T1A_OFF = RC_RING + 308 * 128;                           // T1_0 | T1_2
-constexpr int RC_PD_OFF = RC_T1A_OFF + 308 * RC_T1R;                       // p once more, in slot order (240 compact rows of 128 B): block 0's downsample operand
-constexpr int RC_LDS = RC_PD_OFF + 240 * 128;
+constexpr int RC_LDS = RC_T1A_OFF + 308 * RC_T1R;
 static_assert(240 * RC_T1R <= 308 * 128 && RC_LDS <= 163840, "LDS map");
 constexpr int RC_NF = 520, RC_NG = RC_NF / 8;
 constexpr int S_A0 = 0, S_B0 = 10, S_B1 = 190, S_B2 = 338;               // segment bases (fragment indices)
@@ -80,34 +83,72 @@ __device__ __forceinline__ void slot_pos(int s, int& dy, int& dx) {
 }
 __device__ __forceinline__ bool slot_used(int s) { return s < 180 || (s >= 192 && s < 252); }
 
-// the weight ring: groups of 8 fragments, RC_GROUPS slots; boundary() is called in front of the first read of a group
+// the weight ring: groups of 8 fragments, RC_GROUPS slots; boundary<J>() runs in front of the first read of the tile's group J.
+// PERSIST: a workgroup walks over several tiles and the ring does not stop at a tile boundary - the groups behind a tile's last one are
+// the NEXT tile's first ones - and 10 boundaries of block 2 (from J = RC_AUX0) also carry one "aux" piece each: the next tile's p halo
+// (P aliases t1_1, which is dead from block 2 on).  Counted waits: a boundary needs ITS group's two
+// pieces; younger than those are the pieces of the three following groups (6) plus the aux pieces of the three boundaries before it.
+// A tile ends with vmcnt(0) + its global stores (stores count in vmcnt and may complete early: no counted wait may rely on them), so the
+// first RC_LEAD boundaries of a following tile wait for nothing - their groups were in flight before the drain.
+constexpr int RC_AUX0 = 43, RC_NAUX = 10;
+template <bool PERSIST>
 struct Ring {
     __amdgpu_buffer_rsrc_t rs;
     unsigned char* lds;
     unsigned lds_base, vcur;
-    int wave, vpiece, gi, slot;
-    __device__ __forceinline__ void issue_group(int g, int s) {          // this wave's two pieces of group g into ring slot s
+    int wave, lane, vpiece, slot;
+    int first, has_next;                       // first tile of this workgroup; a next tile exists
+    const bf16_t* nX;                          // next tile: frame base and origin
+    int ny0, nx0;
+    const bf16_t* zeros;
+    template <int G>
+    __device__ __forceinline__ void issue_group(int s) {          // this wave's two pieces of (tile-local) group G into ring slot s
         unsigned char* dst = lds + s * RC_GB + wave * 2048;
-        const int so = g < RC_NG ? g * RC_GB : RC_NG * RC_GB;             // behind the tile's last group: out of range (zeros, no access)
+        int so;
+        if constexpr (G < RC_NG) so = G * RC_GB;
+        else if constexpr (PERSIST) so = has_next ? (G - RC_NG) * RC_GB : RC_NG * RC_GB;
+        else so = RC_NG * RC_GB;                                   // behind the last group: out of range (zeros, no memory access)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vpiece, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, vpiece + 1024, so, 0, 0);
     }
+    // p halo group g (8 raster rows of 14 x 22) / slot-ordered group g (8 compact rows) of the tile at (X, y0, x0)
+    __device__ __forceinline__ void p_piece(const bf16_t* X, int y0, int x0, int g, bool live) {
+        const int rsub = lane >> 3, cpos = lane & 7;
+        const int row = g * 8 + rsub;
+        const int hy = row / 22, hx = row - hy * 22;
+        const int y = y0 - 3 + hy, x = x0 - 3 + hx;
+        const bool ok = live && y >= 0 && y < 64 && x >= 0 && x < 64;
+        const bf16_t* src = ok ? X + ((size_t)y * 64 + x) * 64 + (cpos ^ ((row >> 1) & 7)) * 8 : zeros;
+        if (row < 308) dma16(src, lds + RC_P_OFF + g * 1024);        // (the last group is half a piece: EXEC masks the rows beyond the raster)
+    }
+    template <int K>
+    __device__ __forceinline__ void aux() {            // aux piece K of this wave (a piece that does not exist repeats the one before)
+        int g = wave + 4 * K;
+        if (g >= 39) g -= 4;
+        p_piece(nX, ny0, nx0, g, has_next != 0);
+    }
+    template <int J>
     __device__ __forceinline__ void boundary() {
-        wait_vmcnt<6>();                       // this wave's pieces of the group being opened have landed (three groups may be in flight)
+        constexpr bool isaux = PERSIST && J >= RC_AUX0 && J < RC_AUX0 + RC_NAUX;
+        constexpr int W = RC_LEAD - 1;                                       // groups in flight behind the one being opened
+        constexpr int lo = J - W > RC_AUX0 ? J - W : RC_AUX0, hi = J < RC_AUX0 + RC_NAUX ? J : RC_AUX0 + RC_NAUX;
+        constexpr int nauxb = PERSIST && hi > lo ? hi - lo : 0;           // aux boundaries among J - W .. J - 1
+        if constexpr (PERSIST && J < RC_LEAD) { if (first) wait_vmcnt<2 * W>(); }
+        else wait_vmcnt<2 * W + nauxb>();
         pin();
-        __builtin_amdgcn_s_barrier();          // ... everybody's have; and everybody has consumed the group two behind: its slot is free
+        __builtin_amdgcn_s_barrier();          // everybody's pieces of group J have landed; everybody has consumed group J - 2: its slot is free
         pin();
-        int s4 = slot + 4;
+        int s4 = slot + RC_LEAD;
         if (s4 >= RC_GROUPS) s4 -= RC_GROUPS;
-        issue_group(gi + 4, s4);
-        vcur = lds_base + slot * RC_GB + (vpiece & 1023);
-        gi += 1;
+        issue_group<J + RC_LEAD>(s4);
+        if constexpr (isaux) aux<J - RC_AUX0>();
+        vcur = lds_base + slot * RC_GB + lane * 16;
         slot = slot + 1 == RC_GROUPS ? 0 : slot + 1;
         pin();
     }
     template <int F>
     __device__ __forceinline__ u32x4 rd() {
-        if constexpr (F % 8 == 0) boundary();
+        if constexpr (F % 8 == 0) boundary<F / 8>();
         return lds_read_b128_o<(F % 8) * 1024>(vcur);
     }
 };
@@ -115,10 +156,11 @@ struct Ring {
 // ---------------------------------------------------------------- one bottleneck behind its conv1
 // in : t1 raster (width SRCW, origin OFS pixels up-left of the 3x3's own region), y = residual (packed B fragments) of NPT pixel tiles
 // out: y (in place), acc = the next conv1's pre-activations: [pixel tile][channel tile] (NM = 2 or 4 channel tiles)
-// DS (block 0): no residual; conv3 = [conv3 | downsample], the second K half on p fragments read at pd[i] (the lane's row of the PD image, key pk[i])
-template <int NPT, int SRCW, int SEG, int NM, bool DS>
-__device__ __forceinline__ void chain_block(Ring& ring, unsigned (&y)[2][64], const unsigned (&rb)[2], const u32x4 (&idf)[2], const u32x4& ones,
-                                            f32x16 (&acc)[NPT * NM], const unsigned (&pd)[2], const unsigned (&pk)[2], int lhalf) {
+// DS (block 0): no residual; conv3 = [conv3 | downsample], the second K half on the p fragments ps[pixel tile][k-step]
+// side(S): called once per k-step S of the next conv1's loop (block 2 stores y2 there)
+template <int NPT, int SRCW, int SEG, int NM, bool DS, typename RingT, typename SideT>
+__device__ __forceinline__ void chain_block(RingT& ring, unsigned (&y)[2][64], const unsigned (&rb)[2], const u32x4 (&idf)[2], const u32x4& ones,
+                                            f32x16 (&acc)[NPT * NM], const u32x4 (&ps)[2][4], SideT&& side) {
     constexpr int D = RC_DEPTH;
     constexpr int CS = DS ? 9 : 5, O_B1 = O_C3 + 8 * CS;
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -171,13 +213,6 @@ __device__ __forceinline__ void chain_block(Ring& ring, unsigned (&y)[2][64], co
             constexpr int M = decltype(mc)::value, J = decltype(jc)::value;
             c[M & 1][J] = ring.template rd<SEG + O_C3 + CS * M + J>();
         };
-        u32x4 ps[NPT][4];
-        if constexpr (DS) {
-#pragma unroll
-            for (int i = 0; i < NPT; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) ps[i][ks] = lds_read_b128(pd[i] + (((2 * ks + lhalf) ^ pk[i]) << 4));
-        }
         sfor<0, CS>([&](auto jc) { rdc(IC<0>{}, jc); });
         auto epi_t2 = [&](auto ic, auto mc, auto hc) {          // half (8 values -> 4 registers) of t2 tile (pixel tile I, channel tile M)
             constexpr int I = decltype(ic)::value, M = decltype(mc)::value, H = decltype(hc)::value;
@@ -274,6 +309,7 @@ __device__ __forceinline__ void chain_block(Ring& ring, unsigned (&y)[2][64], co
                     lgkm<full + (more ? M : 0) - (NM * S + M) - 1>();
                     acc[M] = mfma_bf16(w[buf][M], *reinterpret_cast<u32x4*>(&y[0][4 * S]), acc[M]);
                     if constexpr (more) rdw(IC<S + D>{}, mc);
+                    if constexpr (M == 1) side(sc);
                     pin();
                     if constexpr (NPT == 2) { acc[NM + M] = mfma_bf16(w[buf][M], *reinterpret_cast<u32x4*>(&y[1][4 * S]), acc[NM + M]); pin(); }
                 });
@@ -305,7 +341,7 @@ __device__ __forceinline__ void tile_to_rows(const unsigned (&q)[8], u32x4& lo, 
 }
 }  // namespace
 
-template <bool YS2>
+template <bool YS2, bool PERSIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void res2_chain_kernel(Res2ChainArgs kargs) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[RC_LDS];
     const Res2ChainArgs& p = kargs;
@@ -314,38 +350,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lrow = lane & 31, lhalf = lane >> 5;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const bf16_t* zeros = static_cast<const bf16_t*>(p.zeros);
-    const int ntiles = p.B * 32, wslot0 = xcd_remap(blockIdx.x, gridDim.x);
-    if (wslot0 >= ntiles) return;
-    const int tile = p.rev ? ntiles - 1 - wslot0 : wslot0;
-    const int b = tile >> 5, y0 = ((tile & 31) >> 2) * 8, x0 = (tile & 3) * 16;
-    const bf16_t* X = static_cast<const bf16_t*>(p.x) + (size_t)b * 64 * 64 * 64;
+    const int ntiles = p.B * 32, G = gridDim.x;
+    const int L = xcd_remap(blockIdx.x, G);          // consecutive logical ids on one XCD: concurrent neighbours share their halos through that L2
+    if (L >= ntiles) return;
+    const int nk = PERSIST ? (ntiles - L + G - 1) / G : 1;
+    auto tile_of = [&](int k) { const int idx = L + k * G; return p.rev ? ntiles - 1 - idx : idx; };
+    int b, y0, x0;
+    const bf16_t* X;
+    auto set_tile = [&](int t) {
+        b = t >> 5; y0 = ((t & 31) >> 2) * 8; x0 = (t & 3) * 16;
+        X = static_cast<const bf16_t*>(p.x) + (size_t)b * 64 * 64 * 64;
+    };
+    set_tile(tile_of(0));
+    // phase stamps (probe only; PERSIST: of the workgroup's second tile).  s_memtime is a scalar-memory instruction: it shares lgkmcnt with
+    // the LDS reads and returns out of order, so it is waited for at once - never outstanding beside a counted fragment wait
+    unsigned long long stamps[7];
+    const int kstamp = nk > 1 ? 1 : 0;
+    int kcur = 0;
+    auto stamp = [&](int i) {
+        if (p.ts && kcur == kstamp) { stamps[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    };
 
-    // ---------------- p halo: 14 x 22 raster, 39 groups of 8 rows (128 B, chunks XOR (row >> 1) & 7) by LDS-DMA; then the ring's first groups
-    {
-        const int rsub = lane >> 3, cpos = lane & 7;
-        for (int g = wave; g < 39; g += 4) {
-            const int row = g * 8 + rsub;
-            const int hy = row / 22, hx = row - hy * 22;
-            const int y = y0 - 3 + hy, x = x0 - 3 + hx;
-            const bool ok = row < 308 && y >= 0 && y < 64 && x >= 0 && x < 64;
-            const bf16_t* src = ok ? X + ((size_t)y * 64 + x) * 64 + (cpos ^ ((row >> 1) & 7)) * 8 : zeros;
-            dma16(src, lds + RC_P_OFF + g * 1024);
-        }
-        // p once more, in slot order (block 0's downsample operand): 30 groups of 8 compact rows
-        for (int g = wave; g < 30; g += 4) {
-            const int rc = g * 8 + rsub;
-            int dy, dx;
-            slot_pos(rc < 180 ? rc : rc + 12, dy, dx);
-            const int y = y0 + dy, x = x0 + dx;
-            const bool ok = y >= 0 && y < 64 && x >= 0 && x < 64;
-            const bf16_t* src = ok ? X + ((size_t)y * 64 + x) * 64 + (cpos ^ ((rc >> 1) & 7)) * 8 : zeros;
-            dma16(src, lds + RC_PD_OFF + g * 1024);
-        }
-    }
-    Ring ring;
+    Ring<PERSIST> ring;
     ring.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wstream), 0, RC_NG * RC_GB, 0x00020000);
-    ring.lds = lds; ring.lds_base = lds_base; ring.wave = wave; ring.vpiece = wave * 2048 + lane * 16; ring.gi = 0; ring.slot = 0; ring.vcur = 0;
-    ring.issue_group(0, 0); ring.issue_group(1, 1); ring.issue_group(2, 2); ring.issue_group(3, 3);
+    ring.lds = lds; ring.lds_base = lds_base; ring.wave = wave; ring.lane = lane; ring.vpiece = wave * 2048 + lane * 16; ring.slot = 0; ring.vcur = 0;
+    ring.first = 1; ring.has_next = 0; ring.nX = X; ring.ny0 = 0; ring.nx0 = 0; ring.zeros = zeros;
+    // ---------------- the first tile's p halo (14 x 22 raster, 39 groups of 8 rows of 128 B, chunks XOR (row >> 1) & 7) by LDS-DMA; then the
+    // ring's first groups
+    if (kstamp == 0) stamp(0);
+    for (int g = wave; g < 39; g += 4) ring.p_piece(X, y0, x0, g, true);
+    sfor<0, RC_LEAD>([&](auto gc) { ring.template issue_group<decltype(gc)::value>(decltype(gc)::value); });
 
     // constant fragments: identity halves (A operand), ones (B operand of the bias MFMAs)
     u32x4 idf[2], ones;
@@ -369,6 +403,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto inframe = [&](int dy, int dx) { const int yy = y0 + dy, xx = x0 + dx; return (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) ? 0xffffffffu : 0u; };
 
     unsigned y[2][64];          // [pixel tile][k-step t: 4 t .. 4 t + 3]: channels 16 t + pi(8 h + e)
+    u32x4 ps[2][4];             // p at the wave's slots: block 0's downsample operand, taken out of the halo raster at the end of A0
+    auto noside = [](auto) {};
+  for (int k = 0; k < nk; ++k) {
+    kcur = k;
+    if (PERSIST) {
+        ring.first = k == 0;
+        ring.has_next = k + 1 < nk;
+        if (k + 1 < nk) {
+            const int t = tile_of(k + 1);
+            ring.nX = static_cast<const bf16_t*>(p.x) + (size_t)(t >> 5) * 64 * 64 * 64;
+            ring.ny0 = ((t & 31) >> 2) * 8; ring.nx0 = (t & 3) * 16;
+        }
+        if (k == kstamp && k > 0) stamp(0);
+    }
     // ================================================================ A0: t1_0 = relu(b1 + W1 p) on the 14 x 22 raster
     {
         const bool three = wave < 2;                     // raster pixel tiles wave, wave + 4, wave + 8 (< 10)
@@ -379,9 +427,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             prow[i] = lds_base + RC_P_OFF + hr * 128;
             pkey[i] = (hr >> 1) & 7;
         }
-        const u32x4 bf0 = ring.rd<S_A0>(), bf1 = ring.rd<S_A0 + 1>();        // (the first boundary: the halo is older than the ring's pieces)
+        const u32x4 bf0 = ring.template rd<S_A0>(), bf1 = ring.template rd<S_A0 + 1>();        // (the first boundary: the halo is older than the ring's pieces)
+        if (p.ts) { lgkm<0>(); stamp(1); }
         u32x4 wa[4][2];
-        sfor<0, 4>([&](auto kc) { constexpr int KS = decltype(kc)::value; wa[KS][0] = ring.rd<S_A0 + 2 + 2 * KS>(); wa[KS][1] = ring.rd<S_A0 + 3 + 2 * KS>(); });
+        sfor<0, 4>([&](auto kc) { constexpr int KS = decltype(kc)::value; wa[KS][0] = ring.template rd<S_A0 + 2 + 2 * KS>(); wa[KS][1] = ring.template rd<S_A0 + 3 + 2 * KS>(); });
         f32x16 a1[3][2];
         lgkm<8>();
 #pragma unroll
@@ -402,6 +451,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 a1[i][1] = mfma_bf16(wa[KS][1], pf[KS & 1][i], a1[i][1]);
             }
         });
+        // p at the wave's slots, for block 0 (the raster dies at the barrier below: t1_1 takes its place)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hr = (pdy[i] + 3) * 22 + pdx[i] + 3;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ps[i][ks] = lds_read_b128(lds_base + RC_P_OFF + hr * 128 + (((2 * ks + lhalf) ^ ((hr >> 1) & 7)) << 4));
+        }
         // conv1's epilogue: raster stores
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -416,22 +472,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         lds_wait();
         __builtin_amdgcn_s_barrier();                // t1_0 complete, P dead
         pin();
+        stamp(2);
     }
     // ================================================================ block 0 (12 x 20 region: all eight tiles)
     {
         unsigned rb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) rb[i] = lds_base + RC_T1A_OFF + ((pdy[i] + 2) * 22 + pdx[i] + 2) * RC_T1R + lhalf * 16;
-        unsigned pd[2], pk[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int sl = (4 * i + wave) * 32 + lrow;
-            const int rc = sl < 180 ? sl : ((sl >= 192 && sl < 252) ? sl - 12 : 0);
-            pd[i] = lds_base + RC_PD_OFF + rc * 128;
-            pk[i] = (rc >> 1) & 7;
-        }
         f32x16 acc[4];
-        chain_block<2, 22, S_B0, 2, true>(ring, y, rb, idf, ones, acc, pd, pk, lhalf);
+        chain_block<2, 22, S_B0, 2, true>(ring, y, rb, idf, ones, acc, ps, noside);
         const unsigned a0 = lds_base + RC_T1B_OFF + ((pdy[0] + 2) * 20 + pdx[0] + 2) * RC_T1R + 8 * lhalf;
         const unsigned a1 = used1 ? lds_base + RC_T1B_OFF + ((pdy[1] + 2) * 20 + pdx[1] + 2) * RC_T1R + 8 * lhalf : 0xffffffffu;
         const unsigned m1 = inframe(pdy[1], pdx[1]);
@@ -440,6 +489,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         lds_wait();
         __builtin_amdgcn_s_barrier();                // t1_1 complete, t1_0 dead
         pin();
+        stamp(3);
     }
     // ================================================================ block 1 (10 x 18 region: tiles 0 .. 5; waves 2, 3 own one)
     {
@@ -449,56 +499,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned a0 = lds_base + RC_T1A_OFF + ((pdy[0] + 1) * 18 + pdx[0] + 1) * RC_T1R + 8 * lhalf;
         if (wave < 2) {
             f32x16 acc[4];
-            chain_block<2, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, rb, rb, lhalf);
+            chain_block<2, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, ps, noside);
             const unsigned a1 = used1 ? lds_base + RC_T1A_OFF + ((pdy[1] + 1) * 18 + pdx[1] + 1) * RC_T1R + 8 * lhalf : 0xffffffffu;
             const unsigned m1 = inframe(pdy[1], pdx[1]);
             store_t1(acc[0], a0, 0xffffffffu, 0); store_t1(acc[1], a0, 0xffffffffu, 1);
             store_t1(acc[2], a1, m1, 0); store_t1(acc[3], a1, m1, 1);
         } else {
             f32x16 acc[2];
-            chain_block<1, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, rb, rb, lhalf);
+            chain_block<1, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, ps, noside);
             store_t1(acc[0], a0, 0xffffffffu, 0); store_t1(acc[1], a0, 0xffffffffu, 1);
         }
         lds_wait();
-        __builtin_amdgcn_s_barrier();                // t1_2 complete, t1_1 dead
+        __builtin_amdgcn_s_barrier();                // t1_2 complete, t1_1 dead: the next tile's p halo may land in its place
         pin();
+        stamp(4);
     }
     // ================================================================ block 2 (the 8 x 16 tile) + res3's conv1 (256 -> 128)
     {
         unsigned rb[2];
         rb[0] = rb[1] = lds_base + RC_T1A_OFF + (pdy[0] * 18 + pdx[0]) * RC_T1R + lhalf * 16;
         f32x16 acc[4];
-        chain_block<1, 18, S_B2, 4, false>(ring, y, rb, idf, ones, acc, rb, rb, lhalf);
-        wait_vmcnt<0>();                             // the phantom groups behind the last one are out of the queue
+        // y2 (256 channels of the lane's pixel; YS2: the even pixels only, compactly) leaves under the MFMAs of res3's conv1, one 16-byte
+        // piece per lane and k-step: a CU's write path takes ~ 10 B/clk, the tile's 48 KB of output would otherwise be a tail of ~ 4 k cycles
+        const bool mine = !YS2 || (((pdy[0] | pdx[0]) & 1) == 0);
+        bf16_t* YO = YS2 ? static_cast<bf16_t*>(p.y) + (((size_t)b * 32 + ((y0 + pdy[0]) >> 1)) * 32 + ((x0 + pdx[0]) >> 1)) * 256 + 8 * lhalf
+                         : static_cast<bf16_t*>(p.y) + (((size_t)b * 64 + y0 + pdy[0]) * 64 + x0 + pdx[0]) * 256 + 8 * lhalf;
+        u32x4 ylo, yhi;
+        auto y2side = [&](auto sc) {
+            constexpr int S = decltype(sc)::value, m = S >> 1;
+            if constexpr ((S & 1) == 0) {
+                unsigned q[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = y[0][8 * m + i];
+                tile_to_rows(q, ylo, yhi);
+                if (mine) *reinterpret_cast<u32x4*>(YO + 32 * m) = ylo;
+            } else {
+                if (mine) *reinterpret_cast<u32x4*>(YO + 32 * m + 16) = yhi;
+            }
+        };
+        chain_block<1, 18, S_B2, 4, false>(ring, y, rb, idf, ones, acc, ps, y2side);
+        // everything this wave has in flight lands: the phantom groups behind the last one (or the next tile's first groups and p halo), y2
+        wait_vmcnt<0>();
+        stamp(5);
         // t1out: 128 channels of the lane's pixel
         bf16_t* T1O = static_cast<bf16_t*>(p.t1out) + ((size_t)b * 64 * 64 + (size_t)(y0 + pdy[0]) * 64 + x0 + pdx[0]) * 128 + 8 * lhalf;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             unsigned q[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) q[k] = relu2_bf16(acc[m][2 * k], acc[m][2 * k + 1]);
+            for (int i = 0; i < 8; ++i) q[i] = relu2_bf16(acc[m][2 * i], acc[m][2 * i + 1]);
             u32x4 lo, hi;
             tile_to_rows(q, lo, hi);
             *reinterpret_cast<u32x4*>(T1O + 32 * m) = lo;
             *reinterpret_cast<u32x4*>(T1O + 32 * m + 16) = hi;
         }
-        // y2: 256 channels of the lane's pixel (YS2: the even pixels only, compactly)
-        const bool mine = !YS2 || (((pdy[0] | pdx[0]) & 1) == 0);
-        bf16_t* YO = YS2 ? static_cast<bf16_t*>(p.y) + (((size_t)b * 32 + ((y0 + pdy[0]) >> 1)) * 32 + ((x0 + pdx[0]) >> 1)) * 256 + 8 * lhalf
-                         : static_cast<bf16_t*>(p.y) + (((size_t)b * 64 + y0 + pdy[0]) * 64 + x0 + pdx[0]) * 256 + 8 * lhalf;
+    }
+    if (p.ts && k == kstamp) {
+        if (!PERSIST) wait_vmcnt<0>();
+        stamp(6);
+        if (tid == 0) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            unsigned q[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) q[k] = y[0][8 * m + k];
-            u32x4 lo, hi;
-            tile_to_rows(q, lo, hi);
-            if (mine) {
-                *reinterpret_cast<u32x4*>(YO + 32 * m) = lo;
-                *reinterpret_cast<u32x4*>(YO + 32 * m + 16) = hi;
-            }
+            for (int i = 0; i < 7; ++i) p.ts[(size_t)blockIdx.x * 8 + i] = stamps[i];
         }
     }
+    if (PERSIST && k + 1 < nk) set_tile(tile_of(k + 1));
+  }
 }
 
 // ---------------------------------------------------------------- the fragment stream (pack time)
@@ -556,12 +621,25 @@ void launch_res2_chain_pack(const Res2ChainPackArgs& a, hipStream_t st) {
 bool res2_chain_ok(const Res2ChainArgs& a) { return a.x && a.y && a.t1out && a.wstream && a.zeros && a.B > 0; }
 
 void launch_res2_chain(const Res2ChainArgs& a, hipStream_t st) {
-    const int grid = a.B * 32;                      // one 8 x 16 tile per workgroup
+    // persistent form (tunable R2C_PERSIST, default on): one workgroup per CU walks over its tiles (8 x 16 pixels each) with the weight ring
+    // running across the tile boundaries and the next tile's p halo prefetched during block 2; R2C_GRID workgroups (0 = one per CU)
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipDeviceProp_t pr; (void)hipGetDevice(&dev); ncu = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    const int ntiles = a.B * 32;
+    const bool persist = tune_get("R2C_PERSIST", 1) != 0;
+    int gmax = tune_get("R2C_GRID", 0);
+    if (gmax <= 0) gmax = ncu;
+    const int grid = persist ? std::min(ntiles, gmax) : ntiles;
     ConvArgs d{};
     d.B = a.B; d.H = 64; d.W = 64; d.Ho = 64; d.Wo = 64; d.Cin = 64; d.Cout = 256; d.KH = -2; d.KW = -2; d.stride = 1;   // KH = -2: the res2 stage row of the layer report
     void* tok = prof_begin(d, 2, st);
-    if (a.y_s2) hipLaunchKernelGGL((res2_chain_kernel<true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((res2_chain_kernel<false>), dim3(grid), dim3(256), 0, st, a);
+    if (persist) {
+        if (a.y_s2) hipLaunchKernelGGL((res2_chain_kernel<true, true>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((res2_chain_kernel<false, true>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (a.y_s2) hipLaunchKernelGGL((res2_chain_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((res2_chain_kernel<false, false>), dim3(grid), dim3(256), 0, st, a);
+    }
     prof_end(tok, st);
 }
 

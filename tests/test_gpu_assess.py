@@ -490,11 +490,13 @@ def test_conv1_forwarding_through_res2_is_bit_identical(dev, net16):
         net = net16 if chunk == 0 else make_net(dev, "bf16", chunk=chunk)
         got = {}
         try:
+            L.tune_set(b"RES2_CHAIN", 0)      # the stage / per-block kernels (the register-chained default has its own summation orders)
             for mode in (1, 0):
                 L.tune_set(b"FWD2", mode)
                 got[mode] = [net.forward_tap(ttf, ttp, nm)[1].clone() for nm in ("res2", "res3")] + [net(ttf, ttp).clone()]
         finally:
             L.tune_set(b"FWD2", 1)
+            L.tune_set(b"RES2_CHAIN", 1)
         for a, b, nm in zip(got[1], got[0], ("res2", "res3", "scores")):
             assert torch.equal(a, b), (B, chunk, nm, (a.float() - b.float()).abs().max().item())
 

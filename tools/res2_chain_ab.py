@@ -52,6 +52,21 @@ try:
         print(f"round {r}: B = {B}: chain {a:8.1f} us   stage {b:8.1f} us   ({100 * (a - b) / b:+.1f} %)   chain {2 * B * 1006632960 / a / 1e6:.0f} algorithmic TFLOP/s")
 finally:
     L.tune_set(b"RES2_CHAIN", 1)
+# phase timeline of the chain kernel (wave 0's stamps, mean over the workgroups)
+ts = torch.zeros(B * 32, 8, device=dev, dtype=torch.int64)
+L.tune_set(b"RES2_CHAIN", 1)
+y, t1 = out[1]
+for _ in range(3):
+    L.check(lib.ivosw_res2_stage_probe(L.dptr(packed), L.dptr(x), L.dptr(y), L.dptr(t1), B, 1, L.dptr(ts), st), "probe")
+torch.cuda.synchronize()
+t = ts.cpu().numpy().astype(np.float64)[:, :7]
+t = t[t[:, 6] > 0]          # (the persistent form stamps one tile per workgroup: one row per CU)
+d = np.diff(t, axis=1).mean(axis=0)
+names = ["prologue: halo + first group", "A0 (conv1 on 14 x 22)", "block 0", "block 1", "block 2 + res3 conv1", "stores"]
+mf = [0, 3 * 9, 2 + 144 + 8 * 17 + 2 + 64, 2 + 144 + 8 * 13 + 2 + 64, 2 + 72 + 8 * 7 + 4 + 64, 0]        # MFMAs of the busiest wave
+for n, c, m in zip(names, d, mf):
+    print(f"  {n:32s} {c:8.0f} cycles   ({m * 32:6d} of MFMA issue)")
+print(f"  {'total':32s} {(t[:, 6] - t[:, 0]).mean():8.0f} cycles   ({sum(mf) * 32:6d})")
 for i, nm in enumerate(("y2 (even pixels)", "t1out")):
     a, b = out[1][i].float(), out[0][i].float()
     print(f"{nm}: max |chain - stage| = {(a - b).abs().max().item():.4f} of max {b.abs().max().item():.2f}; mean {(a - b).abs().mean().item():.2e} of mean {b.abs().mean().item():.3f}")
