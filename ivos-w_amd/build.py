@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libivosw_hip.so")
-SOURCES = ["capi.cpp", "brain.hip", "dqn.hip", "assess_front.hip", "conv.hip", "bottleneck.hip", "bottleneck_wide.hip", "res2_stage.hip", "res2_chain.hip", "stage_first.hip", "stem.hip", "assess.hip", "metrics.hip", "seg_epilogue.hip", "p2p.hip"]  # missing files are skipped
+SOURCES = ["capi.cpp", "brain.hip", "dqn.hip", "assess_front.hip", "conv.hip", "bottleneck.hip", "bottleneck_wide.hip", "res2_stage.hip", "res2_chain.hip", "gemm_8phase.hip", "stage_first.hip", "stem.hip", "assess.hip", "metrics.hip", "seg_epilogue.hip", "p2p.hip"]  # missing files are skipped
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # per-file flags: res2_chain.hip runs one wave per SIMD (512 registers) and wants its MFMA accumulators in VGPRs (no v_accvgpr_read per
 # epilogue value: - 10 % on the block body, tools/ubench/chain_bench.hip)

@@ -296,7 +296,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 extern "C" int ivosw_assess_split(int dtype, int B, int chunk) { return split_wanted(dtype, B, chunk, 0) ? 1 : 0; }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
-    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|stage_first*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
+    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|res2_chain*|gemm_8phase*|stage_first*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
 static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,
@@ -485,7 +485,8 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 q.B = nb; q.H = hin; q.W = hin; q.Cin = c.Cin; q.Ho = hout; q.Wo = hout; q.Cout = c.Cout;
                 q.KH = c.K; q.KW = c.K; q.stride = c.stride; q.pad = c.pad; q.relu = relu;
                 q.rev = next_dir();
-                if (dtype == IVOSW_BF16 && c.fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + c.fw_off, st);
+                if (dtype == IVOSW_BF16 && tune_get("G8", 0) && tune_get("WIDE1X1", 1) && conv1x1_g8_ok(q)) launch_conv1x1_g8(q, st);
+                else if (dtype == IVOSW_BF16 && c.fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + c.fw_off, st);
                 else launch_conv(q, dtype, false, st);
             };
             if (dtype == IVOSW_BF16 && bp.f1_off && tune_get("FUSE_WIDE", 1)) {
@@ -618,7 +619,8 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 q.x2 = x; q.Cin2 = cd.Cin; q.H2 = hw; q.W2 = hw; q.stride2 = cd.stride;
                 q.rev = next_dir();
                 if (s == 1 && ys2) { q.H2 = hw / 2; q.W2 = hw / 2; q.stride2 = 1; }      // res2's output arrives already subsampled
-                if (dtype == IVOSW_BF16 && bp.cat_fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + bp.cat_fw_off, st);
+                if (dtype == IVOSW_BF16 && tune_get("G8", 0) && tune_get("WIDE1X1", 1) && conv1x1_g8_ok(q)) launch_conv1x1_g8(q, st);
+                else if (dtype == IVOSW_BF16 && bp.cat_fw_off && conv1x1_wide_ok(q) && tune_get("WIDE1X1", 1)) launch_conv1x1_wide(q, base + bp.cat_fw_off, st);
                 else launch_conv(q, dtype, false, st);
                 x = y;
                 hw = ho;

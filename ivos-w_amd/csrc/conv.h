@@ -144,6 +144,9 @@ bool bneck_wide_fusable(const BneckWideArgs& a);
 void launch_bneck_wide(const BneckWideArgs& a, hipStream_t st);
 void launch_fragpack(const void* w, int Cout, int K, void* out, hipStream_t st);
 // bf16 1x1 convolution (optionally with the K-extension x2) on fragment-ordered weights `fw` (bottleneck_wide.hip)
+// the same layers on the 256 x 256 8-phase contraction (gemm_8phase.hip): plain K-major weights a.w
+bool conv1x1_g8_ok(const ConvArgs& a);
+void launch_conv1x1_g8(const ConvArgs& a, hipStream_t st);
 bool conv1x1_wide_ok(const ConvArgs& a);
 void launch_conv1x1_wide(const ConvArgs& a, const void* fw, hipStream_t st);
 

@@ -25,6 +25,10 @@
 //     behind it): while one wave of a SIMD issues its 16 MFMAs its partner issues reads and DMA.
 //   * K-tiles that do not exist (the run-ahead behind the last one) are staged out of range of the buffer descriptor: no memory
 //     access, zeros, the counted waits never change.  K % 128 == 0.
+//   * Tower use: an optional second pixel source supplies the upper K-tiles (a first block's conv3 | downsample: the block input sampled
+//     at stride 2), an optional residual is added in the epilogue, and the weight rows of a half-tile are staged in a permuted order so
+//     that a lane's four result tiles are 16 consecutive output channels of ONE pixel (two 16-byte stores; 8-byte stores cost 30 % of the
+//     layer at K = 768, profiles/r06_gemm_8phase_v1.txt).
 #pragma once
 #include "mfma_tile.h"
 
@@ -33,14 +37,19 @@ namespace ivosw {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 struct G8Args {
-    const bf16_t* A;      // [M][K] K-major (pixels)
-    const bf16_t* B;      // [N][K] K-major (weights)
+    const bf16_t* A;      // [M][K1] K-major (pixels)
+    const bf16_t* B;      // [N][K] K-major (weights), K = K1 + K2
     const float* bias;    // [N]
     bf16_t* C;            // [M][ldc]
-    const bf16_t* R;      // optional residual [M][ldc], added before the ReLU
-    int M, N, K, ldc;     // M % 256 == 0 (rows beyond M: descriptor bounds), N % 256 == 0, K % 128 == 0
+    const bf16_t* R;      // optional residual [M][ldc], added before the ReLU (RES)
+    int M, N, K, ldc;     // N % 256 == 0, K % 128 == 0, K1 % 64 == 0; rows beyond M are not stored (their operand rows read zeros)
     int relu;
     unsigned long long* ts;   // optional [workgroups][4] stamps: s_memtime start / after the K loop / end, s_memrealtime span
+    // K-extension (a first block's conv3 | downsample as one contraction): K-tiles from K1 / 64 on come from A2, a tensor
+    // [frames][H2][W2][K2] sampled at (oy * stride2, ox * stride2) for output pixel (oy, ox) of a Wo x Ho frame; K1 = K and A2 = null: none
+    const bf16_t* A2;
+    int K1, K2, Ho, Wo, H2, W2, stride2;
+    int rev;              // tiles in descending order (tunable SNAKE)
 };
 
 constexpr int G8_HALF = 16384;            // one half-tile
@@ -63,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8phase_kernel(G8Args p) {
     const int wr = wave >> 2, wc = wave & 3;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int nbn = p.N / 256;
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int L0 = xcd_remap(blockIdx.x, gridDim.x), L = p.rev ? (int)gridDim.x - 1 - L0 : L0;
     const int tile_n = L % nbn, tile_m = L / nbn;
     const int m0 = tile_m * 256, n0 = tile_n * 256;
     const int NK = p.K / 64;
@@ -71,31 +80,52 @@ __global__ __launch_bounds__(512, 2) void gemm_8phase_kernel(G8Args p) {
     if (p.ts) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- staging: wave w fills row group w (16 rows) of a half-tile, both k halves (two 1-KB sub-tiles)
-    const int abytes = min(256, p.M - m0) * p.K * 2, bbytes = 256 * p.K * 2;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A) + (size_t)m0 * p.K, 0, abytes, 0x00020000);
+    // A: local row lr of half h is tile row (lr >> 6) * 128 + h * 64 + (lr & 63).  B: local row lr = (wc, nt, 4 cq + r) of half h is
+    // column wc * 64 + 16 cq + 8 h + 4 nt + r, so that a lane's four result tiles (h, nt) hold 16 CONSECUTIVE output channels of its pixel
+    const int K1 = p.K1, NK1 = K1 / 64;
+    const long arows = min(256, p.M - m0);
+    const unsigned abytes = (unsigned)(arows * K1 * 2), bbytes = 256u * p.K * 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A) + (size_t)m0 * K1, 0, abytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B) + (size_t)n0 * p.K, 0, bbytes, 0x00020000);
-    int voA, voB;
+    // the second pixel source: whole tensor in range of one descriptor (< 4 GB), rows addressed per lane
+    const unsigned a2bytes = p.A2 ? (unsigned)min((size_t)0xfffffff0u, (size_t)((p.M + p.Ho * p.Wo - 1) / (p.Ho * p.Wo)) * p.H2 * p.W2 * p.K2 * 2) : 0u;
+    const __amdgpu_buffer_rsrc_t ra2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A2 ? p.A2 : p.A), 0, a2bytes, 0x00020000);
+    int voA, voB, voA2 = 0, hstepA2 = 0;
     {
         const int prow = lane >> 2, pch = lane & 3;
         const int lch = (ABL & 64) ? pch : (pch ^ ((prow >> 3) << 1));
         const int lr = wave * 16 + prow;                      // row of the half-tile
-        voA = ((lr >> 6) * 128 + (lr & 63)) * p.K * 2 + lch * 16;
-        voB = ((lr >> 5) * 64 + (lr & 31)) * p.K * 2 + lch * 16;
+        const int trow = (lr >> 6) * 128 + (lr & 63);         // tile row (half 0)
+        voA = trow * K1 * 2 + lch * 16;
+        const int wi = lr & 31;
+        voB = ((lr >> 5) * 64 + 16 * ((wi & 15) >> 2) + 4 * (wi >> 4) + (wi & 3)) * p.K * 2 + lch * 16;
+        if (p.A2) {
+            const int hw = p.Ho * p.Wo;
+            auto off2 = [&](int m) { const int f = m / hw, q = m - f * hw, oy = q / p.Wo, ox = q - oy * p.Wo;
+                                     return (unsigned)((((size_t)f * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.K2 * 2); };
+            const int m = m0 + trow;
+            voA2 = (int)(m < p.M ? off2(m) : 0xfffffff0u) + lch * 16;     // rows beyond M: out of range, zeros
+            hstepA2 = (int)(off2(m0 + 64) - off2(m0));                     // uniform: 64 rows further is a whole number of raster rows / frames
+        }
     }
-    const int hstepA = 64 * p.K * 2, hstepB = 32 * p.K * 2;
+    const int hstepA = 64 * K1 * 2, hstepB = 8 * p.K * 2;
     // stage half-tile (op: 0 = A, 1 = B; h) of K-tile kt into buffer kt & 1
     // (the instruction's immediate offset is added to the global address AND to the LDS address M0 points at: the second piece's
     // destination is therefore given 64 bytes low)
     auto stage = [&](int kt, int op, int h) {
         unsigned char* dst = lds + (kt & 1) * G8_BUF + (op * 2 + h) * G8_HALF + wave * 2048;
         if (op) {
-            const int so = kt < NK ? kt * 128 + h * hstepB : bbytes;
+            const int so = kt < NK ? kt * 128 + h * hstepB : (int)bbytes;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)dst, 16, voB, so, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(dst + 1024 - 64), 16, voB, so, 64, 0);
-        } else {
-            const int so = kt < NK ? kt * 128 + h * hstepA : abytes;
+        } else if (kt < NK1) {
+            const int so = kt * 128 + h * hstepA;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)dst, 16, voA, so, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(dst + 1024 - 64), 16, voA, so, 64, 0);
+        } else {
+            const int so = kt < NK ? (kt - NK1) * 128 + h * hstepA2 : (int)0x7ffffff0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra2, (lptr_t)dst, 16, voA2, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra2, (lptr_t)(dst + 1024 - 64), 16, voA2, so, 64, 0);
         }
     };
 
@@ -225,29 +255,38 @@ __global__ __launch_bounds__(512, 2) void gemm_8phase_kernel(G8Args p) {
                     for (int d = 0; d < 2; ++d) s += acc[a][b][c][d][0] + acc[a][b][c][d][1] + acc[a][b][c][d][2] + acc[a][b][c][d][3];
         if (s == 1.2345e33f) p.C[lane] = 1;
     } else {
+        // a lane holds 16 consecutive channels (16 cq + 8 nh + 4 nt + r) of pixel px in its four tiles (nh, nt): two 16-byte stores per
+        // pixel tile, the four lanes of a pixel cover a whole 128-byte line
         const int cq = lane >> 4, px = lane & 15;
+        const int n = n0 + wc * 64 + 16 * cq;
+        float4 bv[2][2];
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = n0 + wc * 64 + nh * 32 + nt * 16 + 4 * cq;
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            for (int nt = 0; nt < 2; ++nt) bv[nh][nt] = *reinterpret_cast<const float4*>(p.bias + n + 8 * nh + 4 * nt);
 #pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
+        for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const int m = m0 + wr * 128 + mh * 64 + mt * 16 + px;
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wr * 128 + mh * 64 + mt * 16 + px;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float v[8];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
                         const f32x4_t a = acc[mh][nh][mt][nt];
-                        float v0 = a[0] + bv.x, v1 = a[1] + bv.y, v2 = a[2] + bv.z, v3 = a[3] + bv.w;
-                        if (RES) {
-                            const u32x2 r = *reinterpret_cast<const u32x2*>(p.R + (size_t)m * p.ldc + n);
-                            v0 += __uint_as_float(r[0] << 16); v1 += __uint_as_float(r[0] & 0xffff0000u);
-                            v2 += __uint_as_float(r[1] << 16); v3 += __uint_as_float(r[1] & 0xffff0000u);
-                        }
-                        const u32x2 o = {act2_bf16(v0, v1, p.relu != 0), act2_bf16(v2, v3, p.relu != 0)};
-                        if (!(ABL & 4)) *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
-                        else if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u) *reinterpret_cast<u32x2*>(p.C + (size_t)m * p.ldc + n) = o;
+                        v[4 * nt] = a[0] + bv[nh][nt].x; v[4 * nt + 1] = a[1] + bv[nh][nt].y; v[4 * nt + 2] = a[2] + bv[nh][nt].z; v[4 * nt + 3] = a[3] + bv[nh][nt].w;
                     }
+                    if (RES) {
+                        const u32x4 r = *reinterpret_cast<const u32x4*>(p.R + (size_t)m * p.ldc + n + 8 * nh);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(r[j] << 16); v[2 * j + 1] += __uint_as_float(r[j] & 0xffff0000u); }
+                    }
+                    const u32x4 o = {act2_bf16(v[0], v[1], p.relu != 0), act2_bf16(v[2], v[3], p.relu != 0), act2_bf16(v[4], v[5], p.relu != 0), act2_bf16(v[6], v[7], p.relu != 0)};
+                    if (!(ABL & 4)) *reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + n + 8 * nh) = o;
+                    else if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(p.C + (size_t)m * p.ldc + n + 8 * nh) = o;
+                }
             }
     }
     if (p.ts && tid == 0) {

@@ -273,6 +273,37 @@ def test_wide_1x1_conv_matches_tiled_kernel(dev, net16):
             np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
 
 
+def test_8phase_layer_kernel_matches_the_wide_kernel_and_the_fp32_path(dev, net16, net32):
+    """bf16 mode, round 6: the K-heavy 1x1 layers on the 256 x 256 8-phase contraction (gemm_8phase.hip, tunable G8=1; off by default -
+    at the tower's shapes it ties the wide kernel, see the file header:
+    two waves per SIMD staggered by a barrier, counted vmcnt, both operands by LDS-DMA, plain K-major weights) against
+    conv1x1_wide_kernel (G8=0): same operands and roundings, different fp32 accumulation order - compared at the bf16
+    tolerance, and the 8-phase path must sit as close to the fp32 path as the wide kernel does.  B = 3 exercises the M tail (192
+    res5 pixels in a 256-pixel tile, with the stride-2 second pixel source of [conv3 | downsample])."""
+    from ivos_w_amd import _lib as L
+    lib = L.lib()
+    for B, edge in ((8, True), (3, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        for nm in ("res4", "res5"):
+            ref = net32.forward_tap(ttf, ttp, nm)[1].float()
+            try:
+                L.tune_set(b"G8", 1)
+                _, a = net16.forward_tap(ttf, ttp, nm)
+                sa = net16(ttf, ttp).cpu().numpy()
+                L.tune_set(b"G8", 0)
+                _, b = net16.forward_tap(ttf, ttp, nm)
+                sb = net16(ttf, ttp).cpu().numpy()
+            finally:
+                L.tune_set(b"G8", 0)
+            a, b = a.float(), b.float()
+            scale = ref.abs().max().item()
+            ea, eb = (a - ref).abs().mean().item() / scale, (b - ref).abs().mean().item() / scale
+            assert (a - b).abs().max().item() <= 2e-2 * scale, (nm, (a - b).abs().max().item() / scale)
+            assert not torch.equal(a, b), nm            # (the two kernels really are different code paths)
+            assert ea <= max(1.25 * eb, 1e-4), (nm, ea, eb)
+            np.testing.assert_allclose(sa, sb, rtol=BF16_SCORE_RTOL)
+
+
 def test_chained_res4_blocks_are_bit_identical_to_separate_launches(dev, net16):
     """bf16 mode: res4's five identity blocks chained inside one launch (tunable STAGE_RUN=1, default; the workgroup that
     wrote a frame is its only reader, workgroup-scope release / acquire between blocks) against one launch per block:

@@ -1,5 +1,3 @@
-python -m pytest tests/test_gpu_assess.py -x -q 2>&1 | tail -5
-python bench.py --steps 40 --warmup 5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'], d['roofline'].get('family_ms'))"
-IVOSW_TUNE_RES2_CHAIN=0 python bench.py --steps 40 --warmup 5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'])"
-python bench.py --steps 40 --warmup 5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'])"
-IVOSW_TUNE_R2C_PERSIST=0 python bench.py --steps 40 --warmup 5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'])"
+python -m pytest tests/test_gpu_assess.py -q 2>&1 | tail -12
+python bench.py --steps 20 --warmup 3 --no-clock-probe --no-live-traffic --no-cpu-baseline --no-fp32 --layer-report gpurun_out/r06_layers_g8.txt 2>&1 | tail -1 | cut -c1-200
+IVOSW_TUNE_G8=0 python bench.py --steps 20 --warmup 3 --no-clock-probe --no-live-traffic --no-cpu-baseline --no-fp32 --layer-report gpurun_out/r06_layers_g8off.txt 2>&1 | tail -1 | cut -c1-200

@@ -108,7 +108,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dbias, bias.data(), N * 4, hipMemcpyHostToDevice));
         a.A = (const bf16_t*)dA; a.B = (const bf16_t*)dB; a.bias = (const float*)dbias; a.C = (bf16_t*)dC; a.R = nullptr;
-        a.M = M; a.N = N; a.K = K; a.ldc = N; a.relu = 1;
+        a.M = M; a.N = N; a.K = K; a.ldc = N; a.relu = 1; a.K1 = K; a.A2 = nullptr;
         // correctness first, and again after the timed runs (a race that needs load to show); the un-staggered form too
         CK(hipMemset(dC, 0xff, (size_t)M * N * 2));
         hipLaunchKernelGGL(gemm_8phase_kernel<0>, dim3(grid), dim3(512), 0, 0, a);
