@@ -39,7 +39,6 @@ SIGNATURES = {
     "ivosw_p2p_allreduce": (_i, [_p, _p, _i, _i, _i, C.POINTER(_p), C.c_uint, _i, _p]),
     "ivosw_p2p_allreduce_clamp_adam": (_i, [_p, _p, _i, _i, _i, C.POINTER(_p), C.c_uint, _i, _p, _p, _p, _i] + [_f] * 6 + [_p]),
     "ivosw_replay_gather": (_i, [_p] * 8 + [_i, _i] + [_p] * 5 + [_p]),
-    "ivosw_lstm_probe": (_i, [_p, _p]),
     "ivosw_replay_draw_state_bytes": (_sz, []),
     "ivosw_replay_draw_index": (C.c_ulonglong, [C.c_ulonglong, C.c_uint, C.c_uint, _i]),
     "ivosw_replay_draw_gather": (_i, [_p] * 8 + [_i, _i, _i] + [_p] * 6 + [_p]),
@@ -68,14 +67,22 @@ SIGNATURES = {
     "ivosw_profile_report": (_i, [C.c_char_p, _sz]),
     "ivosw_tune_set": (_i, [C.c_char_p, _i]),
     "ivosw_ablation_build": (_i, []),
+    "ivosw_clock_probe": (_i, [_p, _i, _p]),
+    "ivosw_assess_forget": (_i, [_p]),
+}
+
+# the tuning probes (include/ivosw_probe.h) live in a superset build of the same sources, libivosw_probe.so: never part of the product ABI
+PROBE_LIB_PATH = os.path.join(_HERE, "libivosw_probe.so")
+PROBE_SIGNATURES = {
+    "ivosw_lstm_probe": (_i, [_p, _p]),
     "ivosw_bneck_probe": (_i, [_p] * 11 + [_i] * 5 + [_p, _p]),
     "ivosw_bneck_wide_probe": (_i, [_p] * 9 + [_i] * 5 + [_p, _p]),
     "ivosw_res2_stage_probe": (_i, [_p] * 4 + [_i] * 2 + [_p, _p]),
     "ivosw_gemm_bt_probe": (_i, [_p] * 4 + [_i] * 4 + [_p, _p]),
-    "ivosw_clock_probe": (_i, [_p, _i, _p]),
 }
 
 _lib = None
+_probe = None
 
 
 def available():
@@ -96,6 +103,30 @@ def lib():
             fn = getattr(h, name)           # AttributeError if the library lacks a declared symbol
             fn.restype, fn.argtypes = res, args
         _lib = h
+    return _lib
+
+
+def probe_lib():
+    """libivosw_probe.so: every entry of the product library plus the probes of include/ivosw_probe.h (tools/, one GPU test)."""
+    global _probe
+    if _probe is None:
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise RuntimeError(f"ivos_w_amd: {PROBE_LIB_PATH} not found - build it with `python ivos-w_amd/build.py`")
+        h = C.CDLL(PROBE_LIB_PATH)
+        for name, (res, args) in list(SIGNATURES.items()) + list(PROBE_SIGNATURES.items()):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _probe = h
+    return _probe
+
+
+def use_probe_lib():
+    """Tuning tools: route EVERY library call of this process through the probe build (the probes steer state inside the library - stamp
+    pointers, tunables - that the product entries called afterwards read).  Call before anything else touches the library."""
+    global _lib
+    if _lib is not None and _lib is not _probe:
+        raise RuntimeError("use_probe_lib() must run before the first library call of the process")
+    _lib = probe_lib()
     return _lib
 
 

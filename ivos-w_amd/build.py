@@ -8,6 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libivosw_hip.so")
+PROBE_LIB = os.path.join(HERE, "libivosw_probe.so")     # superset build with the tuning probes of include/ivosw_probe.h (tools/, one GPU test)
+PROBE_SOURCES = ["assess.hip", "bottleneck.hip", "bottleneck_wide.hip", "brain.hip"]      # the translation units that hold a probe entry
 SOURCES = ["capi.cpp", "brain.hip", "dqn.hip", "assess_front.hip", "conv.hip", "bottleneck.hip", "bottleneck_wide.hip", "res2_stage.hip", "res2_chain.hip", "gemm_8phase.hip", "stage_first.hip", "stem.hip", "assess.hip", "metrics.hip", "seg_epilogue.hip", "p2p.hip"]  # missing files are skipped
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # per-file flags: res2_chain.hip runs one wave per SIMD (512 registers) and wants its MFMA accumulators in VGPRs (no v_accvgpr_read per
@@ -42,6 +44,10 @@ def build(force=False, verbose=True):
         if force or _stale(obj, [src] + headers):
             cmd = [_hipcc()] + FLAGS + EXTRA.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
+        if s in PROBE_SOURCES:                      # the same unit once more with the probe entries compiled in
+            pobj = os.path.join(OBJ, s + ".probe.o")
+            if force or _stale(pobj, [src] + headers):
+                jobs.append([_hipcc()] + FLAGS + EXTRA.get(s, []) + ["-DIVOSW_PROBES=1", "-c", src, "-o", pobj])
 
     def run(cmd):
         if verbose:
@@ -56,6 +62,9 @@ def build(force=False, verbose=True):
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    pobjs = [os.path.join(OBJ, s + (".probe.o" if s in PROBE_SOURCES else ".o")) for s in srcs]
+    if force or jobs or _stale(PROBE_LIB, pobjs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROBE_LIB] + pobjs)
     return LIB
 
 

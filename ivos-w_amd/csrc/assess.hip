@@ -6,6 +6,9 @@
 // ~7 TB/s against ~6 TB/s from HBM (tools/ubench/dma_bench), while small launches cost occupancy, so the bf16
 // default is as large as the benchmark batch.  In bf16 mode the stride-1 bottlenecks of res2 run as ONE fused kernel
 // each (bottleneck.hip); everything else is layer by layer (conv.hip).
+#ifdef IVOSW_PROBES
+#include "../../include/ivosw_probe.h"
+#endif
 #include <limits.h>
 #include <algorithm>
 #include <vector>
@@ -184,11 +187,30 @@ static void pack_dtype_record(const void* packed, int dtype) {
         if (e.first == packed) { e.second = dtype; return; }
     g_pack_dtype.emplace_back(packed, dtype);
 }
-static int pack_dtype_lookup(const void* packed) {           // -1: not packed by this process (e.g. a copied arena): not checkable
+// The check covers arenas whose tag this process knows: packed here (recorded at pack time) or seen before.  An address the table does not
+// hold - an arena filled by a device copy, or through the C ABI from another library instance - is looked up ONCE in the arena itself (the
+// 4-byte device tag, a blocking copy on the caller's stream: first use only) and cached.  -1: no valid tag, not checkable.
+// ivosw_assess_forget() drops an address when its memory is freed or reused for an arena of another precision by a device copy.
+static int pack_dtype_lookup(const void* packed, hipStream_t st = nullptr) {
+    {
+        std::lock_guard<std::mutex> lock(g_pack_mu);
+        for (auto& e : g_pack_dtype)
+            if (e.first == packed) return e.second;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return -1;      // no blocking copy inside a capture
+    unsigned tag = 0;
+    const char* slot = static_cast<const char*>(packed) + plan_for(IVOSW_BF16).norm_off + 6 * sizeof(float);     // (norm_off is the same in every plan)
+    if (hipMemcpyAsync(&tag, slot, sizeof(tag), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    const int dtype = (tag >> 16) == 0x4956u && (int)(tag & 0xffffu) <= IVOSW_F32X3 ? (int)(tag & 0xffffu) : -1;
+    if (dtype >= 0) pack_dtype_record(packed, dtype);
+    return dtype;
+}
+extern "C" int ivosw_assess_forget(const void* packed) {
     std::lock_guard<std::mutex> lock(g_pack_mu);
-    for (auto& e : g_pack_dtype)
-        if (e.first == packed) return e.second;
-    return -1;
+    for (size_t i = 0; i < g_pack_dtype.size(); ++i)
+        if (g_pack_dtype[i].first == packed) { g_pack_dtype.erase(g_pack_dtype.begin() + i); return IVOSW_OK; }
+    return IVOSW_OK;
 }
 
 extern "C" size_t ivosw_assess_packed_bytes(int dtype) {
@@ -368,7 +390,7 @@ static int assess_forward_impl(const void* packed, int dtype, const float* tf, c
     IVOSW_REQUIRE(tap_stage >= 0 && tap_stage <= 8, "tap_stage out of range");
     IVOSW_REQUIRE(tap_stage == 0 || tap_out, "tap_out is null");
     {
-        const int packed_for = pack_dtype_lookup(packed);
+        const int packed_for = pack_dtype_lookup(packed, as_stream(stream));
         IVOSW_REQUIRE(packed_for < 0 || packed_for == dtype, "the arena was packed for another dtype (ivosw_assess_pack's dtype must be the forward call's)");
     }
     const bool want_split = split_wanted(dtype, B, chunk, tap_stage);
@@ -685,6 +707,7 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
     }
 }
 
+#ifdef IVOSW_PROBES
 // Tuning probe: one launch of the res2 stage kernel on x [B,64,64,64] bf16 with the weights of a packed bf16 arena; y [B,64,64,256]
 // (y_s2: [B,32,32,256]), t1out [B,64,64,128]; ts (may be NULL): [B*32][16] s_memtime stamps at the phase boundaries.
 extern "C" int ivosw_res2_stage_probe(const void* packed, const void* x, void* y, void* t1out, int B, int y_s2, unsigned long long* ts,
@@ -708,3 +731,4 @@ extern "C" int ivosw_res2_stage_probe(const void* packed, const void* x, void* y
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
+#endif  // IVOSW_PROBES

@@ -21,6 +21,9 @@
 //     written with ds_write_b64 and the final tile goes through a 4-KB per-wave staging tile to 64-B row segments.
 //
 // LDS: [0, 131072) x ring (4 x 32 KB) -> t1 -> t2 ; [131072, 163840) per-wave store staging (8 x 4 KB).
+#ifdef IVOSW_PROBES
+#include "../../include/ivosw_probe.h"
+#endif
 #include <type_traits>
 
 #include "conv.h"
@@ -2212,6 +2215,7 @@ void launch_bneck_wide_stage(const BneckStageArgs& s_in, hipStream_t st) {
 
 }  // namespace ivosw
 
+#ifdef IVOSW_PROBES
 // Tuning probe: one wide fused bottleneck launch (weights given K-major packed; fragment-ordered copies are made into
 // `frag`, >= 2 * (Cmid*Cin + 9*Cmid*Cmid + Cin*Cmid) + 256 bytes, the last 256 zero) with phase stamps ts [workgroups][8]
 // (may be NULL).
@@ -2236,7 +2240,9 @@ extern "C" int ivosw_bneck_wide_probe(const void* x, void* y, const void* wa, co
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
+#endif  // IVOSW_PROBES
 
+#ifdef IVOSW_PROBES
 // Tuning probe: the big-register-tile contraction of round 5's attainable-roof measurement (gemm_bt.h) behind the C ABI, so that the
 // kernel the micro-benchmark times is also built into the library and checked by the GPU tests.
 extern "C" int ivosw_gemm_bt_probe(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int relu,
@@ -2253,3 +2259,4 @@ extern "C" int ivosw_gemm_bt_probe(const void* A, const void* B, const float* bi
     IVOSW_CHECK_LAUNCH();
     return IVOSW_OK;
 }
+#endif  // IVOSW_PROBES

@@ -8,6 +8,9 @@
 // walks the T steps with h broadcast from LDS: rows (sample x direction) map to workgroups, so a
 // 128-sample minibatch fills all 256 CUs.  fp32 throughout (exact fma chains); MFMA is used for the
 // dense batched contractions only (gemm_f32.h).
+#ifdef IVOSW_PROBES
+#include "../../include/ivosw_probe.h"
+#endif
 #include <mutex>
 
 #include "gemm_f32.h"
@@ -1646,8 +1649,10 @@ extern "C" int ivosw_dqn_step_drawn(float* policy, const float* target, const fl
 
 /* Tuning probe: subsequent fused forwards stamp s_memtime at four points of recurrence step T/2 per workgroup into ts
  * ([workgroups, 8] uint64 on the device: 0-3 the step's four points, 4 kernel entry, 5 weights in registers, 6 last step done; NULL switches the probe off).  tools/lstm_probe.py. */
+#ifdef IVOSW_PROBES
 extern "C" int ivosw_lstm_probe(unsigned long long* ts, unsigned long long* ts_bwd) {
     g_lstm_probe = ts;
     g_lstm_probe_bwd = ts_bwd;          // BPTT kernel: 0 step start, 1 gate gradients written, 2 barrier passed, 3 matvec done, 4 / 5 loop start / end, 6 steps
     return IVOSW_OK;
 }
+#endif  // IVOSW_PROBES

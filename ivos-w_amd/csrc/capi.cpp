@@ -40,8 +40,8 @@ namespace ivosw {
 // Tunables: fixed table, looked up by name.  Lookups, first-use insertion, tune_set and the one-time environment read are safe from
 // several host threads: a SET value and the cached environment default live in separate atomic fields, so a lookup
 // that is reading the environment can never overwrite a concurrent tune_set; the flags are published with release / acquire.
-// The sources read 47 distinct keys (grep tune_get); the table holds every one of them set at once plus a cache entry per key
-// for the environment default (IVOSW_TUNE_<KEY> is read ONCE per key and process: a forward pass asks for ~40 keys).
+// The sources read ~60 distinct keys (grep tune_get; tests/test_cabi.py sets every one of them plus 40 more); ONE entry per key holds the
+// set value and the cached environment default (IVOSW_TUNE_<KEY> is read ONCE per key and process: a forward pass asks for ~40 keys).
 struct Tunable {
     char key[32];
     std::atomic<int> value;          // ivosw_tune_set
@@ -50,7 +50,7 @@ struct Tunable {
     std::atomic<int> env_state;      // 0 not read yet, 1 absent, 2 present
 };
 constexpr int kMaxTunables = 160;
-static_assert(kMaxTunables >= 3 * 47, "the tunables table must hold every key the sources read, with room to grow");
+static_assert(kMaxTunables >= 2 * 64, "the tunables table must hold every key the sources read (~60, one entry each), with room to grow");
 static Tunable g_tun[kMaxTunables];
 static std::atomic<int> g_ntun{0};
 static std::mutex g_tun_mu;

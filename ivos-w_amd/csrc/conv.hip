@@ -895,7 +895,7 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
             lds_wait();
             if (ks < 3) frag_read(ks + 1, (ks + 1) & 1);
             if ABL(p.debug, 2) {                               // ablation: fragment reads without the MFMAs
-                asm volatile("" ::"v"(fa[ks & 1][0]), "v"(fa[ks & 1][1]), "v"(fb[ks & 1][0]), "v"(fb[ks & 1][1]));
+                asm volatile("" ::"v"(fa[ks & 1][0]), "v"(fa[ks & 1][TM - 1]), "v"(fb[ks & 1][0]), "v"(fb[ks & 1][TN - 1]));      // (TM = 1 in the 2-frame tiling)
                 continue;
             }
 #pragma unroll
@@ -954,8 +954,9 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
 // shapes covered by conv3x3_patch_kernel
 static bool patch3x3_ok(const ConvArgs& a) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.res || a.H != a.W || a.Cin % 64 || a.Cout % 128) return false;
-    // the rule looks at the layer shape only, never at the batch (a frame's result must not depend on the batch it travels in:
-    // B % 4 != 0 at H == 8 used to fall back to the per-tap kernel for the WHOLE launch, i.e. another summation order)
+    // ELIGIBILITY looks at the layer shape only, never at the batch (a frame's result must not depend on the batch it travels in:
+    // B % 4 != 0 at H == 8 used to fall back to the per-tap kernel for the WHOLE launch, i.e. another summation order).  The TILING inside
+    // the patch kernel may depend on B (round 5: 2-frame tiles for small launches) because the 2- and 4-frame tilings share the K order.
     return a.H == 32 || a.H == 16 || a.H == 8;
 }
 

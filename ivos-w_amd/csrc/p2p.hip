@@ -83,7 +83,7 @@ __device__ __forceinline__ bool p2p_wait_all(P2pHeader* h, int world, int parity
         const unsigned long long t0 = wall_clock64();
         const unsigned long long limit = blockIdx.x == 0 ? timeout_ticks : 2 * timeout_ticks;
         while (__hip_atomic_load(&h->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            const unsigned w = __hip_atomic_load(&h->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned w = __hip_atomic_load(&h->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
             if (wall_clock64() - t0 > limit || (w >> 2) == epoch) { state = 2; break; }
             __builtin_amdgcn_s_sleep(8);
         }
@@ -91,11 +91,13 @@ __device__ __forceinline__ bool p2p_wait_all(P2pHeader* h, int world, int parity
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned mine = (epoch << 2) | (state == 1 ? 1u : 2u);
-        unsigned w = __hip_atomic_load(&h->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the verdict word is published and read with release / acquire: a workgroup that adopts an OK verdict it did not
+        // propose itself synchronises with the proposer, who acquire-loaded every flag before proposing
+        unsigned w = __hip_atomic_load(&h->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         while ((w >> 2) != epoch) {                          // undecided for this epoch: propose; whoever swaps first has decided
-            const unsigned seen = atomicCAS(&h->verdict, w, mine);
-            if (seen == w) { w = mine; break; }
-            w = seen;
+            unsigned expect = w;
+            if (__hip_atomic_compare_exchange_strong(&h->verdict, &expect, mine, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) { w = mine; break; }
+            w = expect;
         }
         state = (w & 3u) == 1u ? 1 : 2;
         if (state == 2) atomicExch(&h->error, 1u);
@@ -167,6 +169,7 @@ extern "C" int ivosw_p2p_allreduce_clamp_adam(const float* grads, float* grads_o
     IVOSW_REQUIRE(grads && arenas && params && exp_avg && exp_avg_sq, "null pointer");
     IVOSW_ON_DEVICE_OF(params);
     IVOSW_REQUIRE(n > 0 && world > 0 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world && epoch > 0 && step >= 1, "bad rank / world / epoch / step");
+    IVOSW_REQUIRE(epoch < (1u << 30), "epoch must stay below 2^30: the verdict word packs (epoch << 2) | decision");
     IVOSW_REQUIRE((reinterpret_cast<uintptr_t>(grads) & 15) == 0, "the gradient buffer must be 16-byte aligned");
     P2pPeers peers{};
     for (int r = 0; r < world; ++r) {
@@ -250,6 +253,7 @@ extern "C" int ivosw_p2p_allreduce(const float* grads, float* out, int n, int ra
     IVOSW_REQUIRE(grads && out && arenas, "null pointer");
     IVOSW_ON_DEVICE_OF(out);
     IVOSW_REQUIRE(n > 0 && world > 0 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world && epoch > 0, "bad rank / world / epoch");
+    IVOSW_REQUIRE(epoch < (1u << 30), "epoch must stay below 2^30: the verdict word packs (epoch << 2) | decision");
     IVOSW_REQUIRE(((reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "gradient buffers must be 16-byte aligned");
     P2pPeers peers{};
     for (int r = 0; r < world; ++r) {

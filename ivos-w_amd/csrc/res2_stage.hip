@@ -53,25 +53,13 @@ constexpr int R2_LDS = 163840;
 constexpr int T1R = 144;                             // bytes per padded t1 raster row
 constexpr int P_OFF = 0, T1A_OFF = 39936, SB0_OFF = 84288, PD_OFF = 0, T2A_OFF = 30720, Y0_OFF = 63488, T1B_OFF = 129024;
 constexpr int T2B_OFF = 0, SB1_OFF = 24576, Y1_OFF = 24576, T1C_OFF = 122880;
-#ifndef R2_GROUPS
-#define R2_GROUPS 0                                  // 1: block 2 runs as two independent 4-wave groups (pixel-tile parity = wave >> 2) behind
-#endif                                               // group-local barriers; 2: also C0 / D0's K halves and C1 -> D1
-#if R2_GROUPS
-// block 2 with nothing aliased across the groups: a group may be in C2 / D2 (writing / reading ITS rows of the y image) while the
-// other still reads the t1 raster in its 3x3
-constexpr int Y2_OFF = 0, SB2_OFF = 65536, T2C_OFF = 98304;
-constexpr int GCNT_OFF = 163584;                     // two arrival counters (one per group) in the 256 bytes the map leaves free
-#else
+// (round 4's R2_GROUPS experiment - block 2 as two 4-wave groups behind LDS-counter group barriers: correct, 0.7 - 2.1 % slower, LAB_NOTES
+// round 4 item 1 - was removed from this file in round 6: history, commit "two 4-wave groups behind LDS-counter group barriers")
 constexpr int SB2_OFF = 39936, T2C_OFF = 72704, Y2_OFF = 89088;      // [0, 39936) stays free from B2 on: the NEXT tile's p halo lands there
-#endif
 static_assert(T1A_OFF + 308 * T1R <= SB0_OFF && SB0_OFF + 65536 <= R2_LDS, "A0/B0 map");
 static_assert(PD_OFF + 240 * ROWB <= T2A_OFF && T2A_OFF + 256 * ROWB <= Y0_OFF && Y0_OFF + 65536 <= T1B_OFF && T1B_OFF + 240 * T1R <= R2_LDS, "C0/D0 map");
 static_assert(T2B_OFF + 192 * ROWB <= SB1_OFF && SB1_OFF + 49152 <= T1B_OFF && Y1_OFF + 98304 <= T1C_OFF && T1C_OFF + 180 * T1R <= R2_LDS, "b1 map");
-#if R2_GROUPS
-static_assert(Y2_OFF + 65536 <= SB2_OFF && SB2_OFF + 32768 <= T2C_OFF && T2C_OFF + 128 * ROWB <= T1C_OFF && T1C_OFF + 180 * T1R <= GCNT_OFF && GCNT_OFF + 8 <= R2_LDS, "b2 map (groups)");
-#else
 static_assert( SB2_OFF + 32768 <= T2C_OFF && T2C_OFF + 128 * ROWB <= Y2_OFF && Y2_OFF + 65536 <= R2_LDS && T2C_OFF + 128 * ROWB <= T1C_OFF, "b2 map");
-#endif
 
 __device__ __forceinline__ const uint4* wfr(const void* base, int ct, int KS, int ks, int lane) {
     return reinterpret_cast<const uint4*>(static_cast<const char*>(base) + ((size_t)(ct * KS + ks) * 64 + lane) * 16);
@@ -90,25 +78,6 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-// Barrier of ONE 4-wave group (gfx950 has no named barriers): a monotonic arrival counter in LDS.  A wave's LDS operations execute in
-// order, so its add follows its stores; the waves that see the target see those stores.  `target` = 4 x (barriers so far).
-struct GroupSync {
-    unsigned addr, target;
-    bool lane0;
-    __device__ __forceinline__ void sync() {
-        lds_wait();
-        target += 4;
-        if (lane0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
-        for (;;) {
-            unsigned v;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-            if (__builtin_amdgcn_readfirstlane(v) >= target) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-};
-
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -180,16 +149,12 @@ __device__ __forceinline__ f32x16 mm(u32x4 a, u32x4 b, f32x16 c) {
 // ---------------------------------------------------------------- phase B: 3x3 on a padded raster, NPT pixel tiles of slots
 // t1 raster of width SRCW at T1_OFF -> t2 [slot][128 B swizzled] at T2_OFF; partial sums through SB_OFF.  `ahead` runs between
 // the k-loop and the exchange: the caller requests the next phase's weights there.
-template <int NPT, int SRCW, int DBG, int PER, int DEPTH, bool GSYNC = false, typename FO, typename F>
+template <int NPT, int SRCW, int DBG, int PER, int DEPTH, typename FO, typename F>
 __device__ __forceinline__ void phase_b(unsigned char* lds, unsigned lds_base, int T1_OFF, int T2_OFF, int SB_OFF, WB& wb, int wave,
-                                        int lane, const TilePos& tp, FO&& own, F&& ahead, GroupSync* gs = nullptr) {
+                                        int lane, const TilePos& tp, FO&& own, F&& ahead) {
     constexpr int NT = NPT / 2, OFS = (SRCW - 16) / 2 - 1;
     const int lrow = lane & 31, lhalf = lane >> 5;
-#if R2_GROUPS
-    const int ct = wave & 1, kh = (wave >> 1) & 1, q = wave >> 2;      // the K-half partners (waves w, w ^ 2) sit in one group: parity = wave >> 2
-#else
     const int ct = wave & 1, q = (wave >> 1) & 1, kh = wave >> 2;
-#endif
     f32x16 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -240,7 +205,7 @@ __device__ __forceinline__ void phase_b(unsigned char* lds, unsigned lds_base, i
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(scr + ((i * 4 + g) * 64 + lane) * 4) = make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
         }
-    if constexpr (GSYNC) gs->sync(); else __syncthreads();
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NT; ++i)
         if ((i & 1) == kh) {
@@ -440,29 +405,11 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
     auto stamp = [&](int k) {
         if (p.ts && tid == 0 && stamped) p.ts[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime();
     };
-#if R2_GROUPS
-    int bct = wave & 1, bkh = (wave >> 1) & 1;       // phase B: channel tile, K half (pixel-tile parity = wave >> 2, as in phase C)
-#else
     int bct = wave & 1, bkh = wave >> 2;             // phase B: channel tile, K half
-#endif
     int cc = wave & 3, hh = wave >> 2;               // phase C: channel tiles cc, cc + 4; pixel tiles hh, hh + 2, ...
-#if R2_GROUPS >= 2
-    int dct = wave & 1, dv = 2 * ((wave >> 1) & 1) + (wave >> 2);      // phase D0 / D1: channel tile, pixel tiles dv, dv + 4 of the wave's own parity
-#else
     int dct = wave & 1, dv = wave >> 1;              // phase D0 / D1: channel tile, pixel tiles dv, dv + 4
-#endif
-#if R2_GROUPS
-    GroupSync gsy{lds_base + GCNT_OFF + 4 * (unsigned)(wave >> 2), 0u, lane == 0};
-    if (tid < 2) *reinterpret_cast<unsigned*>(lds + GCNT_OFF + 4 * tid) = 0u;       // ordered before the first use by the prologue barrier
-    auto gbar1 = [&]() { gsy.sync(); };
-#else
     auto gbar1 = [&]() { wg_barrier(); };
-#endif
-#if R2_GROUPS >= 2
-    auto gbar2 = [&]() { gsy.sync(); };
-#else
     auto gbar2 = [&]() { wg_barrier(); };
-#endif
 
     WB wb;
     WC wc[2];
@@ -684,13 +631,8 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
         stamp(8);
     }
     // ================================================================ block 2
-#if R2_GROUPS
-    phase_b<4, 18, DBG, 1, R2_DEPTH2, true>(lds, lds_base, T1C_OFF, T2C_OFF, SB2_OFF, wb, wave, lane, tp, [&](auto k) { own_wb(k, p.fb[2]); },
-                           [&](auto n) { ld_wc(n, I4{}, wc[0], p.fc[2], p.bc[2], cc); }, &gsy);
-#else
     phase_b<4, 18, DBG, 1, R2_DEPTH2>(lds, lds_base, T1C_OFF, T2C_OFF, SB2_OFF, wb, wave, lane, tp, [&](auto k) { own_wb(k, p.fb[2]); },
                            [&](auto n) { ld_wc(n, I4{}, wc[0], p.fc[2], p.bc[2], cc); });
-#endif
     gbar1();                                         // t2 of the group's pixel tiles complete (both channel tiles and K halves are the group's)
     stamp(9);
     static_for<0, 2>([&](auto rc_) {
@@ -738,14 +680,8 @@ __global__ __launch_bounds__(512, 2) void res2_stage_kernel(Res2StageArgs kargs)
         bf16_t* dst[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-#if R2_GROUPS
-            // a group stores the pixels of ITS pixel tiles (g, g + 2): nothing of the other group's rows is read
-            const int item = (tid & 255) + 256 * j, gq = wave >> 2, c16 = item & 31, pl = item >> 5;
-            const int pe = YS2 ? 8 * (gq + 2 * (pl >> 3)) + (pl & 7) : 32 * (gq + 2 * (pl >> 5)) + (pl & 31);
-#else
             const int e = tid + 512 * j;
             const int pe = e >> 5, c16 = e & 31;
-#endif
             int slot;
             if (YS2) {
                 slot = (2 * (pe >> 3)) * 16 + 2 * (pe & 7);

@@ -810,6 +810,26 @@ def test_forward_refuses_an_arena_packed_for_another_dtype(dev):
                                       L.stream_ptr(dev))
         assert rc != 0 and b"packed for another dtype" in lib.ivosw_last_error()
     assert torch.equal(net(ttf, ttp), want)                 # the right dtype still runs
+    # an arena this process did NOT pack at that address - a device copy - is checked against its own 4-byte device tag
+    # (read once, on the first forward call that sees the address), and ivosw_assess_forget() drops a cached tag when the memory is re-used
+    clone = packed.clone()
+    scores = torch.empty(B, dtype=torch.float32, device=dev)
+    for dt, ok in ((L.F32, False), (L.F32X3, True)):
+        nbytes = lib.ivosw_assess_ws_bytes(dt, B, H, W, 0)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        rc = lib.ivosw_assess_forward(L.dptr(clone), dt, L.dptr(ttf), L.dptr(ttp), B, H, W, L.dptr(scores), L.dptr(ws), nbytes, 0, 0, None,
+                                      L.stream_ptr(dev))
+        assert (rc == 0) == ok, (dt, lib.ivosw_last_error())
+    assert torch.equal(scores.reshape(want.shape), want)
+    net32 = make_net(dev, "fp32")
+    p32 = net32._ensure_packed()
+    clone.copy_(p32)                                        # the same address now holds an fp32 arena
+    assert lib.ivosw_assess_forget(L.dptr(clone)) == 0
+    nbytes = lib.ivosw_assess_ws_bytes(L.F32, B, H, W, 0)
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    L.check(lib.ivosw_assess_forward(L.dptr(clone), L.F32, L.dptr(ttf), L.dptr(ttp), B, H, W, L.dptr(scores), L.dptr(ws), nbytes, 0, 0, None,
+                                     L.stream_ptr(dev)), "forward on the re-filled arena")
+    assert torch.equal(scores.reshape(want.shape), net32(ttf, ttp))
 
 
 @pytest.mark.parametrize("M,N,K,relu", [(256, 256, 32, 1), (512, 256, 96, 0), (1024, 512, 768, 1), (256, 768, 160, 1)])
@@ -824,7 +844,7 @@ def test_big_register_tile_contraction_vs_torch(dev, M, N, K, relu):
     B = (torch.randn(N, K, generator=g) / K ** 0.5 * (1 + torch.arange(N)[:, None] % 5 * 0.5)).to(torch.bfloat16).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
     C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
-    L.check(L.lib().ivosw_gemm_bt_probe(L.dptr(A), L.dptr(B), L.dptr(bias), L.dptr(C), M, N, K, relu, None, L.stream_ptr(dev)), "gemm_bt_probe")
+    L.check(L.probe_lib().ivosw_gemm_bt_probe(L.dptr(A), L.dptr(B), L.dptr(bias), L.dptr(C), M, N, K, relu, None, L.stream_ptr(dev)), "gemm_bt_probe")
     want = A.float() @ B.float().t() + bias
     if relu:
         want = torch.relu(want)

@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ivos_w_amd import _lib as L  # noqa: E402
+L.use_probe_lib()          # libivosw_probe.so: the product entries + the tuning probes (include/ivosw_probe.h)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 Cm = int(sys.argv[2]) if len(sys.argv) > 2 else 256      # 256: res4 frame kernel, 128 / 64: halo kernels of res3 / res2

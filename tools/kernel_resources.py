@@ -25,7 +25,9 @@ def kernel_table(lib=None):
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(td, f)], capture_output=True, text=True).stdout
             for blk in notes.split("- .agpr_count:")[1:]:
                 get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
-                name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+                # the kernel's own name: the metadata's `.symbol:` (minus `.kd`), not the first `.name:` (an argument name, should the compiler emit them)
+                sym = re.search(r"\.symbol:\s+(\S+?)\.kd\b", blk)
+                name = sym.group(1) if sym else re.findall(r"\.name:\s+(\S+)", blk)[-1]
                 out[name] = dict(agpr=int(re.match(r"\s*(\d+)", blk).group(1)), vgpr=get("vgpr_count"), sgpr=get("sgpr_count"),
                                  spill=get("vgpr_spill_count"), sspill=get("sgpr_spill_count"), scratch=get("private_segment_fixed_size"),
                                  lds=get("group_segment_fixed_size"))

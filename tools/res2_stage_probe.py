@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ivos_w_amd import _lib as L, synth  # noqa: E402
+L.use_probe_lib()          # libivosw_probe.so: the product entries + the tuning probes (include/ivosw_probe.h)
 from ivos_w_amd.models.assessment import AssessNet  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
