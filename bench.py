@@ -283,6 +283,58 @@ def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=75):
             "hbm_GBps_of_family": round(per_pass / (conv_ms * 1e-3) / 1e9, 1) if conv_ms > 0 else None}
 
 
+def dqn_live_traffic(timeout_s=60):
+    """dqn.roofline.traffic measured in THIS run: the DQN loop re-run in two child processes under `rocprofv3 --pmc
+    FETCH_SIZE` / `--pmc WRITE_SIZE` (counters only), every kernel summed, divided by the number of steps (= launches of the encoder
+    kernel, one per step).  KiB units, FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM).  None when rocprofv3 is missing or a child fails."""
+    import glob
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    pmc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pmc)
+    tmp = tempfile.mkdtemp(prefix="ivosw_pmc_dqn_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    got, per_kernel = {}, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "-d", d, "-o", "c", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--workload", "dqn", "--steps", "96", "--warmup", "8", "--min-warm-s", "0", "--dqn-mode", "plain", "--no-cpu-baseline"]
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                child.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, 9)
+                child.communicate()
+                return None
+            csvs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if child.returncode != 0 or not csvs:
+                return None
+            agg = pmc.load(csvs[0], counter)
+            steps = sum(v[0] for k, v in agg.items() if "enc_fused" in k)
+            if steps <= 0:
+                return None
+            scale = 2.0 if counter == "FETCH_SIZE" else 1.0
+            got[counter] = sum(v[1] for v in agg.values()) * 1024.0 * scale / steps
+            for k, v in agg.items():
+                per_kernel[k.split("(")[0][-48:]] = per_kernel.get(k.split("(")[0][-48:], 0.0) + v[1] * 1024.0 * scale / steps
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:6]
+    return {"traffic": round(got["FETCH_SIZE"] + got["WRITE_SIZE"]), "traffic_read_write_MB_per_step": [round(got["FETCH_SIZE"] / 1e6, 1), round(got["WRITE_SIZE"] / 1e6, 1)],
+            "algorithmic_bytes_per_step": 7.0e6, "traffic_top_kernels_MB_per_step": {k: round(v / 1e6, 1) for k, v in top},
+            "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child runs of `bench.py --workload dqn`, every kernel, "
+                              "per step = per launch of the encoder kernel; FETCH_SIZE x2 gfx950 correction, KiB units)"}
+
+
 def bench_front(args, dev, tf, tp):
     """the assessment front end (mask -> box, ROI crop-resize + normalise) is HBM-bound - timed on its own through
     the two C-ABI entry points on the timed batch; algorithmic bytes = `tp` once for the box pass, and for the crop the source
@@ -1003,6 +1055,10 @@ def main():
             line["dqn"]["cpu_baseline"] = cpu_baseline_dqn()
             if not FORCE_DIST[0] and not args.no_dp_critical_path:
                 line["dqn"]["dp_critical_path"] = dqn_dp_critical_path(line["dqn"]["us_per_step"])
+            if not args.no_live_traffic:
+                dt_live = dqn_live_traffic()
+                if dt_live is not None:
+                    line["dqn"]["roofline"].update(dt_live)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

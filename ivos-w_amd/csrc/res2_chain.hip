@@ -52,6 +52,9 @@ constexpr int O_B2 = 0, O_W2 = 2, O_C3 = 74;
 #ifndef RC_DEPTH
 #define RC_DEPTH 2
 #endif
+#ifndef RC_DEFER
+#define RC_DEFER 1
+#endif
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -96,21 +99,24 @@ struct Ring {
     __amdgpu_buffer_rsrc_t rs;
     unsigned char* lds;
     unsigned lds_base, vcur;
-    int wave, lane, vpiece, slot;
+    int wave, lane, vpiece, slot, sfill;
     int first, has_next;                       // first tile of this workgroup; a next tile exists
     const bf16_t* nX;                          // next tile: frame base and origin
     int ny0, nx0;
     const bf16_t* zeros;
     template <int G>
-    __device__ __forceinline__ void issue_group(int s) {          // this wave's two pieces of (tile-local) group G into ring slot s
-        unsigned char* dst = lds + s * RC_GB + wave * 2048;
-        int so;
-        if constexpr (G < RC_NG) so = G * RC_GB;
-        else if constexpr (PERSIST) so = has_next ? (G - RC_NG) * RC_GB : RC_NG * RC_GB;
-        else so = RC_NG * RC_GB;                                   // behind the last group: out of range (zeros, no memory access)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vpiece, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + 1024), 16, vpiece + 1024, so, 0, 0);
+    __device__ __forceinline__ int group_soff() {                  // stream offset of (tile-local) group G
+        if constexpr (G < RC_NG) return G * RC_GB;
+        else if constexpr (PERSIST) return has_next ? (G - RC_NG) * RC_GB : RC_NG * RC_GB;
+        else return RC_NG * RC_GB;                                   // behind the last group: out of range (zeros, no memory access)
     }
+    template <int G, int Q>
+    __device__ __forceinline__ void issue_piece(int s) {            // piece Q (0 / 1) of this wave's two pieces of group G into ring slot s
+        unsigned char* dst = lds + s * RC_GB + wave * 2048 + Q * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vpiece + Q * 1024, group_soff<G>(), 0, 0);
+    }
+    template <int G>
+    __device__ __forceinline__ void issue_group(int s) { issue_piece<G, 0>(s); issue_piece<G, 1>(s); }
     // p halo group g (8 raster rows of 14 x 22) / slot-ordered group g (8 compact rows) of the tile at (X, y0, x0)
     __device__ __forceinline__ void p_piece(const bf16_t* X, int y0, int x0, int g, bool live) {
         const int rsub = lane >> 3, cpos = lane & 7;
@@ -127,9 +133,12 @@ struct Ring {
         if (g >= 39) g -= 4;
         p_piece(nX, ny0, nx0, g, has_next != 0);
     }
+    // The pieces a boundary owes (two of group J + RC_LEAD, one aux piece in block 2) are NOT issued at the barrier: an LDS-DMA issue
+    // holds the wave for 50+ cycles, and behind a barrier the matrix pipe of this SIMD has nothing queued (one wave per SIMD) - they go
+    // out behind the reads of the group's fragments 2, 4 and 6, each of which sits right behind an MFMA (RC_DEFER; 0: all at the barrier).
+    // Counted waits: when boundary J waits, the pieces of boundaries J - W .. J - 1 are out (W = RC_LEAD - 1 groups in flight).
     template <int J>
     __device__ __forceinline__ void boundary() {
-        constexpr bool isaux = PERSIST && J >= RC_AUX0 && J < RC_AUX0 + RC_NAUX;
         constexpr int W = RC_LEAD - 1;                                       // groups in flight behind the one being opened
         constexpr int lo = J - W > RC_AUX0 ? J - W : RC_AUX0, hi = J < RC_AUX0 + RC_NAUX ? J : RC_AUX0 + RC_NAUX;
         constexpr int nauxb = PERSIST && hi > lo ? hi - lo : 0;           // aux boundaries among J - W .. J - 1
@@ -138,18 +147,26 @@ struct Ring {
         pin();
         __builtin_amdgcn_s_barrier();          // everybody's pieces of group J have landed; everybody has consumed group J - 2: its slot is free
         pin();
-        int s4 = slot + RC_LEAD;
-        if (s4 >= RC_GROUPS) s4 -= RC_GROUPS;
-        issue_group<J + RC_LEAD>(s4);
-        if constexpr (isaux) aux<J - RC_AUX0>();
         vcur = lds_base + slot * RC_GB + lane * 16;
+        sfill = slot + RC_LEAD;                // the slot group J + RC_LEAD goes to (= the slot of group J - 2)
+        if (sfill >= RC_GROUPS) sfill -= RC_GROUPS;
         slot = slot + 1 == RC_GROUPS ? 0 : slot + 1;
+        if constexpr (!RC_DEFER) owed<J, 0>(), owed<J, 1>(), owed<J, 2>();
         pin();
+    }
+    template <int J, int Q>
+    __device__ __forceinline__ void owed() {
+        if constexpr (Q < 2) issue_piece<J + RC_LEAD, Q>(sfill);
+        else if constexpr (PERSIST && J >= RC_AUX0 && J < RC_AUX0 + RC_NAUX) aux<J - RC_AUX0>();
     }
     template <int F>
     __device__ __forceinline__ u32x4 rd() {
         if constexpr (F % 8 == 0) boundary<F / 8>();
-        return lds_read_b128_o<(F % 8) * 1024>(vcur);
+        const u32x4 v = lds_read_b128_o<(F % 8) * 1024>(vcur);
+        if constexpr (RC_DEFER && F % 8 == 2) owed<F / 8, 0>();
+        if constexpr (RC_DEFER && F % 8 == 4) owed<F / 8, 1>();
+        if constexpr (RC_DEFER && F % 8 == 6) owed<F / 8, 2>();
+        return v;
     }
 };
 
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     Ring<PERSIST> ring;
     ring.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wstream), 0, RC_NG * RC_GB, 0x00020000);
-    ring.lds = lds; ring.lds_base = lds_base; ring.wave = wave; ring.lane = lane; ring.vpiece = wave * 2048 + lane * 16; ring.slot = 0; ring.vcur = 0;
+    ring.lds = lds; ring.lds_base = lds_base; ring.wave = wave; ring.lane = lane; ring.vpiece = wave * 2048 + lane * 16; ring.slot = 0; ring.sfill = 0; ring.vcur = 0;
     ring.first = 1; ring.has_next = 0; ring.nX = X; ring.ny0 = 0; ring.nx0 = 0; ring.zeros = zeros;
     // ---------------- the first tile's p halo (14 x 22 raster, 39 groups of 8 rows of 128 B, chunks XOR (row >> 1) & 7) by LDS-DMA; then the
     // ring's first groups
