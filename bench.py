@@ -262,6 +262,8 @@ def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=75):
             r = child
             csvs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not csvs:
+                if os.environ.get("IVOSW_BENCH_DEBUG"):
+                    print(f"live_traffic: child rc {r.returncode}, csvs {csvs}", file=sys.stderr)
                 return None
             agg = pmc.load(csvs[0], counter)
             n = sum(v[0] for k, v in agg.items() if any(f in k for f in fams))
@@ -274,6 +276,8 @@ def live_traffic(family, launches_per_pass, conv_ms, passes=3, timeout_s=75):
     (nf, rd), (nw, wr) = got["FETCH_SIZE"], got["WRITE_SIZE"]
     rd *= 2.0                                              # gfx950: FETCH_SIZE reports half the bytes of wide streaming reads
     if nf != nw or nf != launches_per_pass * passes:
+        if os.environ.get("IVOSW_BENCH_DEBUG"):
+            print(f"live_traffic: launches {nf} / {nw} against {launches_per_pass} x {passes}", file=sys.stderr)
         return None
     per_pass = (rd + wr) / passes
     return {"traffic": round((rd + wr) / nf), "traffic_bytes_per_step": round(per_pass),

@@ -318,7 +318,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 extern "C" int ivosw_assess_split(int dtype, int B, int chunk) { return split_wanted(dtype, B, chunk, 0) ? 1 : 0; }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
-    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|res2_chain*|gemm_8phase*|stage_first*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
+    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|res2_chain_kernel*|gemm_8phase*|stage_first*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
 static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,

@@ -1,2 +1,1 @@
-python -m pytest tests/test_gpu_assess.py -x -q -k "res2_chain or bf16_scores_vs or full_size or deterministic" 2>&1 | tail -2
-python tools/res2_chain_ab.py 256 3 2>&1 | tail -13
+IVOSW_BENCH_DEBUG=1 python bench.py --no-cpu-baseline --steps 20 --warmup 3 --no-fp32 --no-clock-probe 2>&1 | grep -v "^{" | tail -5

@@ -22,7 +22,7 @@ def load(path, counter):
 
 def main():
     f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-    fams = (sys.argv[3] if len(sys.argv) > 3 else "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain|gemm_8phase|stage_first|conv3x3_patch|stem_pool").split("|")
+    fams = (sys.argv[3] if len(sys.argv) > 3 else "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain_kernel|gemm_8phase|stage_first|conv3x3_patch|stem_pool").split("|")
     fam = "|".join(fams)
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     print("# HBM traffic from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE as reported), KiB -> bytes")

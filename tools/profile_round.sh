@@ -14,7 +14,7 @@ db=$(ls $out/trace/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocprof_summary.py $db > $out/kernel_trace_summary.txt
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- $BENCH > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- $BENCH > $out/bench_write.log 2>&1
-python tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain|gemm_8phase|stage_first|conv3x3_patch|stem_pool" $PASSES $out/pmc_traffic.json > $out/pmc_hbm_traffic.txt
+python tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain_kernel|gemm_8phase|stage_first|conv3x3_patch|stem_pool" $PASSES $out/pmc_traffic.json > $out/pmc_hbm_traffic.txt
 # the un-profiled line (never compare a profiled run with an un-profiled one)
 python bench.py --steps 250 --warmup 10 --layer-report $out/layers.txt > $out/bench.json.log 2>&1
 tail -1 $out/bench.json.log

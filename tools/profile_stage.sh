@@ -12,7 +12,7 @@ db=$(ls $out/trace/*.db 2>/dev/null | head -1)
 [ -n "$db" ] && python tools/rocprof_summary.py $db > $out/kernel_trace_summary.txt
 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f --output-format csv -- $BENCH > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w --output-format csv -- $BENCH > $out/bench_write.log 2>&1
-python tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain|gemm_8phase|stage_first|conv3x3_patch|stem_pool" 5 $out/pmc_traffic.json > $out/pmc_hbm_traffic.txt
+python tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain_kernel|gemm_8phase|stage_first|conv3x3_patch|stem_pool" 5 $out/pmc_traffic.json > $out/pmc_hbm_traffic.txt
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum -d $out/pmc_tcp -o c --output-format csv -- $BENCH > $out/bench_tcp.log 2>&1
 python - <<PY > $out/pmc_tcp_accesses.txt
 import csv, collections

@@ -14,7 +14,7 @@ def demangle(n):
 
 
 def main():
-    db, fam = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain|gemm_8phase|stage_first|conv3x3_patch|stem_pool")
+    db, fam = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "conv_igemm|conv1x1_wide|bneck|res2_stage|res2_chain_kernel|gemm_8phase|stage_first|conv3x3_patch|stem_pool")
     like = " or ".join(f"s.kernel_name like '%{x}%'" for x in fam.split("|"))
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute(
