@@ -1,1 +1,2 @@
-IVOSW_BENCH_DEBUG=1 python bench.py --no-cpu-baseline --steps 20 --warmup 3 --no-fp32 --no-clock-probe 2>&1 | grep -v "^{" | tail -5
+bash tools/profile_round.sh r06a > gpurun_out/profile_round_r06a.log 2>&1
+tail -30 gpurun_out/profile_round_r06a.log
