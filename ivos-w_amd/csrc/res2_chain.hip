@@ -245,14 +245,23 @@ __device__ __forceinline__ void chain_block(RingT& ring, unsigned (&y)[2][64], c
                 for (int q = 0; q < 4; ++q) y[I][8 * M + 4 * H + q] = relu2_bf16(a3[M & 1][I][8 * H + 2 * q], a3[M & 1][I][8 * H + 2 * q + 1]);
             }
         };
+        auto epi_yq = [&](auto mc, auto ic, auto qc) {          // a quarter (4 values -> 2 registers) of y tile (M, pixel tile I)
+            constexpr int M = decltype(mc)::value, I = decltype(ic)::value, Q = decltype(qc)::value;
+            if constexpr (I < NPT) {
+                y[I][8 * M + 2 * Q] = relu2_bf16(a3[M & 1][I][4 * Q], a3[M & 1][I][4 * Q + 1]);
+                y[I][8 * M + 2 * Q + 1] = relu2_bf16(a3[M & 1][I][4 * Q + 2], a3[M & 1][I][4 * Q + 3]);
+            }
+        };
         sfor<0, 8>([&](auto mc) {
             constexpr int M = decltype(mc)::value, cb = M & 1;
             using MP = IC<M - 1>; using MN = IC<M + 1>;
             // filler K of this channel tile: t2's epilogue under tile 0, tile M - 1's y epilogue otherwise
+            // (tile M - 1's epilogue in QUARTERS - 2 v_cvt_pk + 2 v_pk_max - behind MFMAs 2 .. 9 of this tile: a wave alone on its SIMD hides
+            // about five issues per MFMA, sixteen in one gap do not hide)
             auto fill = [&](auto kc) {
                 constexpr int K = decltype(kc)::value;
                 if constexpr (M == 0) { if constexpr (K < 8) epi_t2(IC<((K >> 1) & 1)>{}, IC<(K >> 2)>{}, IC<(K & 1)>{}); }
-                else if constexpr (K >= 2 && K < 6) epi_y(MP{}, IC<((K - 2) >> 1)>{}, IC<((K - 2) & 1)>{});
+                else if constexpr (K >= 2 && K < 2 + 4 * NPT) epi_yq(MP{}, IC<((K - 2) >> 2)>{}, IC<((K - 2) & 3)>{});
             };
             lgkm<CS - 1>();                              // this tile's bias fragment has landed (its weight fragments may not)
             a3[cb][0] = mfma_bf16(c[cb][0], ones, z); fill(IC<0>{}); pin();
@@ -292,8 +301,11 @@ __device__ __forceinline__ void chain_block(RingT& ring, unsigned (&y)[2][64], c
                 lgkm<(M < 7 ? 3 : 0)>();                 // all of this tile's fragments (the three reads of the next tile may be out)
                 sfor<0, 4>([&](auto kc) {
                     constexpr int KS = decltype(kc)::value;
-                    a3[cb][0] = mfma_bf16(c[cb][1 + KS], *reinterpret_cast<u32x4*>(&t2[0][4 * KS]), a3[cb][0]); pin();
+                    a3[cb][0] = mfma_bf16(c[cb][1 + KS], *reinterpret_cast<u32x4*>(&t2[0][4 * KS]), a3[cb][0]);
+                    if constexpr (M > 0) fill(IC<6 + 2 * KS>{});
+                    pin();
                     if constexpr (NPT == 2) { a3[cb][1] = mfma_bf16(c[cb][1 + KS], *reinterpret_cast<u32x4*>(&t2[1][4 * KS]), a3[cb][1]); }
+                    if constexpr (M > 0) fill(IC<7 + 2 * KS>{});
                     if constexpr (M < 7 && KS < 2) rdc(MN{}, IC<3 + KS>{});
                     pin();
                 });

@@ -1,2 +1,2 @@
-bash tools/profile_round.sh r06a > gpurun_out/profile_round_r06a.log 2>&1
-tail -30 gpurun_out/profile_round_r06a.log
+python -m pytest tests/test_gpu_assess.py -x -q -k "res2_chain or bf16_scores_vs" 2>&1 | tail -2
+python tools/res2_chain_ab.py 256 3 2>&1 | tail -13
