@@ -1,2 +1,3 @@
-python -m pytest tests/test_gpu_assess.py -x -q -k "res2_chain or bf16_scores_vs" 2>&1 | tail -2
-python tools/res2_chain_ab.py 256 3 2>&1 | tail -13
+bash tools/pmc_tower.sh > gpurun_out/r06_pmc_tower_survey.txt 2>&1
+tail -14 gpurun_out/r06_pmc_tower_survey.txt
+grep -A 18 "res2_chain_kernel<true, true>" gpurun_out/r06_pmc_tower_survey.txt | head -22

@@ -15,7 +15,7 @@ for f in sorted(glob.glob("gpurun_out/pmc_tower/**/*counter_collection.csv", rec
     for r in csv.DictReader(open(f)):
         a = agg[r["Kernel_Name"]][r["Counter_Name"]]
         a[0] += 1; a[1] += float(r["Counter_Value"])
-fam = ("conv_igemm", "conv1x1_wide", "bneck", "res2_stage", "stage_first", "conv3x3_patch", "stem_pool", "roi_sample", "bbox_scan")
+fam = ("conv_igemm", "conv1x1_wide", "bneck", "res2_stage", "res2_chain_kernel", "gemm_8phase", "stage_first", "conv3x3_patch", "stem_pool", "roi_sample", "bbox_scan")
 for k in sorted(agg):
     if not any(x in k for x in fam):
         continue
