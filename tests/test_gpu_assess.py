@@ -632,6 +632,18 @@ def test_res2_chain_kernel_vs_the_stage_kernel_and_the_fp32_path(dev, net16, net
                 assert ea <= max(1.5 * eb, 2e-3), (B, chunk, nm, ea, eb)
                 assert ma <= max(1.25 * mb, 1e-4), (B, chunk, nm, ma, mb)
         np.testing.assert_allclose(got[1][2].cpu().numpy(), ref[2].cpu().numpy(), rtol=BF16_SCORE_RTOL)
+        # the persistent form (one workgroup per CU walks its tiles, the ring runs across tile boundaries: the default) and one tile per
+        # workgroup (R2C_PERSIST=0) run the same arithmetic per tile: bit-identical; so does a smaller persistent grid (more tiles per workgroup)
+        try:
+            for key, val in ((b"R2C_PERSIST", 0), (b"R2C_GRID", 5)):
+                L.tune_set(key, val)
+                alt = [net.forward_tap(ttf, ttp, nm)[1].float().clone() for nm in ("res2", "res3")] + [net(ttf, ttp).float().clone()]
+                L.tune_set(key, 1 if key == b"R2C_PERSIST" else 0)
+                for a, b, nm in zip(alt, got[1], ("res2", "res3", "scores")):
+                    assert torch.equal(a, b), (key, B, chunk, nm)
+        finally:
+            L.tune_set(b"R2C_PERSIST", 1)
+            L.tune_set(b"R2C_GRID", 0)
 
 
 def test_two_stream_split_is_invisible_in_the_scores(dev, net16, net32):

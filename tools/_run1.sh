@@ -1,3 +1,2 @@
-bash tools/pmc_tower.sh > gpurun_out/r06_pmc_tower_survey.txt 2>&1
-tail -14 gpurun_out/r06_pmc_tower_survey.txt
-grep -A 18 "res2_chain_kernel<true, true>" gpurun_out/r06_pmc_tower_survey.txt | head -22
+python -m pytest tests -m gpu -q 2>&1 | tail -5
+python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
