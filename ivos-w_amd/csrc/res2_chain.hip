@@ -19,12 +19,13 @@
 //     NOT bit-identical to it; tests compare the two at the bf16 tolerance.
 //   * Only the 3x3 inputs go through LDS (padded 144-byte raster rows as in res2_stage.hip).
 //   * EVERY weight fragment (1 KB: lane l = row l & 31, k = 8 (l >> 5) ..) comes through ONE LDS ring per workgroup.  The fragments of a
-//     tile - 520, packed in consumption order by res2_chain_pack_kernel - are fetched by LDS-DMA in groups of 8 (two pieces per wave), four
-//     groups ahead of the group being opened (ring of 6 groups; 8 measured the same); one s_barrier per group, counted s_waitcnt vmcnt: never drained inside a tile.  (res2_stage.hip streams 1.1 MB of
+//     tile - 520, packed in consumption order by res2_chain_pack_kernel - are fetched by LDS-DMA in groups of 16 (four pieces per wave), two
+//     groups ahead of the group being opened (ring of 4 x 16 KB; groups of 8 in a ring of 6 or 8: + 2.8 % cycles - twice the barriers); one s_barrier per
+//     group, counted s_waitcnt vmcnt: never drained inside a tile.  (res2_stage.hip streams 1.1 MB of
 //     fragments per tile into registers through the texture path, every fragment once per wave that needs it; here 520 KB enter the CU once.)
 // Micro-benchmark of the block body behind the go decision: tools/ubench/chain_bench.hip, profiles/r06_chain_bench.txt.
 //
-// LDS (132 928 B): ring [0, 49152) | P (14 x 22 x 128 B, A0 only) / T1_1 (12 x 20 x 144 B) [49152, 88576) | T1_0 (14 x 22 x 144 B) / T1_2
+// LDS (149 312 B): ring [0, 65536) | P (14 x 22 x 128 B, A0 only) / T1_1 (12 x 20 x 144 B) [49152, 88576) | T1_0 (14 x 22 x 144 B) / T1_2
 // (10 x 18 x 144 B) [88576, 132928).
 // Build: this file is compiled with -mllvm -amdgpu-mfma-vgpr-form (build.py): accumulators in VGPRs, no v_accvgpr_read in the epilogues.
 #include <algorithm>
@@ -37,15 +38,19 @@ namespace ivosw {
 
 namespace {
 #ifndef RC_GROUPS_N
-#define RC_GROUPS_N 6
+#define RC_GROUPS_N 4
 #endif
-constexpr int RC_GROUPS = RC_GROUPS_N, RC_LEAD = RC_GROUPS - 2, RC_GB = 8192, RC_RING = RC_GROUPS * RC_GB;   // a group is requested RC_LEAD groups ahead
+#ifndef RC_GF
+#define RC_GF 16                                    // fragments per ring group (one s_barrier per group): 8 | 16
+#endif
+constexpr int RC_GROUPS = RC_GROUPS_N, RC_LEAD = RC_GROUPS - 2, RC_GB = RC_GF * 1024, RC_RING = RC_GROUPS * RC_GB;   // a group is requested RC_LEAD groups ahead
+constexpr int RC_NP = RC_GF / 4;                    // pieces (1 KB) per wave and group
 constexpr int RC_T1R = 144;
 constexpr int RC_P_OFF = RC_RING, RC_T1B_OFF = RC_RING;                   // P | T1_1
 constexpr int RC_T1A_OFF = RC_RING + 308 * 128;                           // T1_0 | T1_2
 constexpr int RC_LDS = RC_T1A_OFF + 308 * RC_T1R;
 static_assert(240 * RC_T1R <= 308 * 128 && RC_LDS <= 163840, "LDS map");
-constexpr int RC_NF = 520, RC_NG = RC_NF / 8;
+constexpr int RC_NF = 520, RC_NG = (RC_NF + RC_GF - 1) / RC_GF;      // (a last partial group is fetched whole: the stream buffer is RC_NG groups long)
 constexpr int S_A0 = 0, S_B0 = 10, S_B1 = 190, S_B2 = 338;               // segment bases (fragment indices)
 // offsets inside a block segment; conv3 takes 5 fragments per channel tile {bias, W3 x 4}, block 0 nine {bias sum, W3 x 4, Wd x 4}
 constexpr int O_B2 = 0, O_W2 = 2, O_C3 = 74;
@@ -93,7 +98,7 @@ __device__ __forceinline__ bool slot_used(int s) { return s < 180 || (s >= 192 &
 // pieces; younger than those are the pieces of the three following groups (6) plus the aux pieces of the three boundaries before it.
 // A tile ends with vmcnt(0) + its global stores (stores count in vmcnt and may complete early: no counted wait may rely on them), so the
 // first RC_LEAD boundaries of a following tile wait for nothing - their groups were in flight before the drain.
-constexpr int RC_AUX0 = 43, RC_NAUX = 10;
+constexpr int RC_AUX0 = RC_GF == 8 ? 43 : 22, RC_NAUX = 10;       // the first boundary of block 2 (fragment 338) and the ten behind it
 template <bool PERSIST>
 struct Ring {
     __amdgpu_buffer_rsrc_t rs;
@@ -112,11 +117,11 @@ struct Ring {
     }
     template <int G, int Q>
     __device__ __forceinline__ void issue_piece(int s) {            // piece Q (0 / 1) of this wave's two pieces of group G into ring slot s
-        unsigned char* dst = lds + s * RC_GB + wave * 2048 + Q * 1024;
+        unsigned char* dst = lds + s * RC_GB + wave * (RC_NP * 1024) + Q * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst, 16, vpiece + Q * 1024, group_soff<G>(), 0, 0);
     }
     template <int G>
-    __device__ __forceinline__ void issue_group(int s) { issue_piece<G, 0>(s); issue_piece<G, 1>(s); }
+    __device__ __forceinline__ void issue_group(int s) { sfor<0, RC_NP>([&](auto qc) { issue_piece<G, decltype(qc)::value>(s); }); }
     // p halo group g (8 raster rows of 14 x 22) / slot-ordered group g (8 compact rows) of the tile at (X, y0, x0)
     __device__ __forceinline__ void p_piece(const bf16_t* X, int y0, int x0, int g, bool live) {
         const int rsub = lane >> 3, cpos = lane & 7;
@@ -142,8 +147,8 @@ struct Ring {
         constexpr int W = RC_LEAD - 1;                                       // groups in flight behind the one being opened
         constexpr int lo = J - W > RC_AUX0 ? J - W : RC_AUX0, hi = J < RC_AUX0 + RC_NAUX ? J : RC_AUX0 + RC_NAUX;
         constexpr int nauxb = PERSIST && hi > lo ? hi - lo : 0;           // aux boundaries among J - W .. J - 1
-        if constexpr (PERSIST && J < RC_LEAD) { if (first) wait_vmcnt<2 * W>(); }
-        else wait_vmcnt<2 * W + nauxb>();
+        if constexpr (PERSIST && J < RC_LEAD) { if (first) wait_vmcnt<RC_NP * W>(); }
+        else wait_vmcnt<RC_NP * W + nauxb>();
         pin();
         __builtin_amdgcn_s_barrier();          // everybody's pieces of group J have landed; everybody has consumed group J - 2: its slot is free
         pin();
@@ -151,21 +156,27 @@ struct Ring {
         sfill = slot + RC_LEAD;                // the slot group J + RC_LEAD goes to (= the slot of group J - 2)
         if (sfill >= RC_GROUPS) sfill -= RC_GROUPS;
         slot = slot + 1 == RC_GROUPS ? 0 : slot + 1;
-        if constexpr (!RC_DEFER) owed<J, 0>(), owed<J, 1>(), owed<J, 2>();
+        if constexpr (!RC_DEFER) sfor<0, RC_NP + 1>([&](auto qc) { owed<J, decltype(qc)::value>(); });
         pin();
     }
     template <int J, int Q>
     __device__ __forceinline__ void owed() {
-        if constexpr (Q < 2) issue_piece<J + RC_LEAD, Q>(sfill);
+        if constexpr (Q < RC_NP) issue_piece<J + RC_LEAD, Q>(sfill);
         else if constexpr (PERSIST && J >= RC_AUX0 && J < RC_AUX0 + RC_NAUX) aux<J - RC_AUX0>();
+    }
+    // the tile's last group may be partial (520 fragments, groups of 16): what it still owes goes out behind the last fragment read
+    __device__ __forceinline__ void finish_tile() {
+        if constexpr (RC_DEFER) {
+            constexpr int RL = (RC_NF - 1) % RC_GF;
+            sfor<0, RC_NP + 1>([&](auto qc) { constexpr int Q = decltype(qc)::value; if constexpr (2 * Q + 2 > RL) owed<RC_NG - 1, Q>(); });
+        }
     }
     template <int F>
     __device__ __forceinline__ u32x4 rd() {
-        if constexpr (F % 8 == 0) boundary<F / 8>();
-        const u32x4 v = lds_read_b128_o<(F % 8) * 1024>(vcur);
-        if constexpr (RC_DEFER && F % 8 == 2) owed<F / 8, 0>();
-        if constexpr (RC_DEFER && F % 8 == 4) owed<F / 8, 1>();
-        if constexpr (RC_DEFER && F % 8 == 6) owed<F / 8, 2>();
+        if constexpr (F % RC_GF == 0) boundary<F / RC_GF>();
+        const u32x4 v = lds_read_b128_o<(F % RC_GF) * 1024>(vcur);
+        constexpr int R = F % RC_GF;                     // the group's pieces behind its fragment reads 2, 4, ...; the aux piece behind the next even one
+        if constexpr (RC_DEFER && R >= 2 && R % 2 == 0 && R / 2 - 1 <= RC_NP) owed<F / RC_GF, R / 2 - 1>();
         return v;
     }
 };
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     Ring<PERSIST> ring;
     ring.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wstream), 0, RC_NG * RC_GB, 0x00020000);
-    ring.lds = lds; ring.lds_base = lds_base; ring.wave = wave; ring.lane = lane; ring.vpiece = wave * 2048 + lane * 16; ring.slot = 0; ring.sfill = 0; ring.vcur = 0;
+    ring.lds = lds; ring.lds_base = lds_base; ring.wave = wave; ring.lane = lane; ring.vpiece = wave * (RC_NP * 1024) + lane * 16; ring.slot = 0; ring.sfill = 0; ring.vcur = 0;
     ring.first = 1; ring.has_next = 0; ring.nX = X; ring.ny0 = 0; ring.nx0 = 0; ring.zeros = zeros;
     // ---------------- the first tile's p halo (14 x 22 raster, 39 groups of 8 rows of 128 B, chunks XOR (row >> 1) & 7) by LDS-DMA; then the
     // ring's first groups
@@ -567,6 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         };
         chain_block<1, 18, S_B2, 4, false>(ring, y, rb, idf, ones, acc, ps, y2side);
+        ring.finish_tile();
         // everything this wave has in flight lands: the phantom groups behind the last one (or the next tile's first groups and p halo), y2
         wait_vmcnt<0>();
         stamp(5);
