@@ -185,10 +185,11 @@ struct Ring {
 // in : t1 raster (width SRCW, origin OFS pixels up-left of the 3x3's own region), y = residual (packed B fragments) of NPT pixel tiles
 // out: y (in place), acc = the next conv1's pre-activations: [pixel tile][channel tile] (NM = 2 or 4 channel tiles)
 // DS (block 0): no residual; conv3 = [conv3 | downsample], the second K half on the p fragments ps[pixel tile][k-step]
-// side(S): called once per k-step S of the next conv1's loop (block 2 stores y2 there)
-template <int NPT, int SRCW, int SEG, int NM, bool DS, typename RingT, typename SideT>
+// side(S): called once per k-step S of the next conv1's loop (block 2 stores y2 there); side3(S): once per k-step of the 3x3 (block 0 stores the
+// previous tile's t1out there)
+template <int NPT, int SRCW, int SEG, int NM, bool DS, typename RingT, typename SideT, typename Side3T>
 __device__ __forceinline__ void chain_block(RingT& ring, unsigned (&y)[2][64], const unsigned (&rb)[2], const u32x4 (&idf)[2], const u32x4& ones,
-                                            f32x16 (&acc)[NPT * NM], const u32x4 (&ps)[2][4], SideT&& side) {
+                                            f32x16 (&acc)[NPT * NM], const u32x4 (&ps)[2][4], SideT&& side, Side3T&& side3) {
     constexpr int D = RC_DEPTH;
     constexpr int CS = DS ? 9 : 5, O_B1 = O_C3 + 8 * CS;
     const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -220,6 +221,7 @@ __device__ __forceinline__ void chain_block(RingT& ring, unsigned (&y)[2][64], c
             lgkm<full - (R * S + 1) - 1>();
             a2[0][0] = mfma_bf16(a[buf][0], b[buf][0], a2[0][0]);
             if constexpr (more) rdstep(SN{}, IC<0>{});
+            side3(sc);
             lgkm<full + (more ? 1 : 0) - (R * S + 2) - 1>();
             a2[0][1] = mfma_bf16(a[buf][1], b[buf][0], a2[0][1]);
             if constexpr (more) { rdstep(SN{}, IC<1>{}); if constexpr (NPT == 1) rdstep(SN{}, IC<2>{}); }
@@ -445,6 +447,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned y[2][64];          // [pixel tile][k-step t: 4 t .. 4 t + 3]: channels 16 t + pi(8 h + e)
     u32x4 ps[2][4];             // p at the wave's slots: block 0's downsample operand, taken out of the halo raster at the end of A0
     auto noside = [](auto) {};
+    // a tile's t1out (8 x 16 bytes per lane) leaves under the NEXT tile's first 3x3 loop, one store per k-step 4 .. 11: issued at the end of
+    // the tile they were a tail of ~ 1.4 k cycles nothing overlapped (a CU's write path takes ~ 10 B/clk); the last tile's are flushed behind the loop
+    u32x4 pend[8];
+    bf16_t* pend_ptr = nullptr;
+    auto t1side = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (S >= 4 && S < 12) {
+            if (pend_ptr) *reinterpret_cast<u32x4*>(pend_ptr + 32 * ((S - 4) >> 1) + 16 * ((S - 4) & 1)) = pend[S - 4];
+        }
+    };
   for (int k = 0; k < nk; ++k) {
     kcur = k;
     if (PERSIST) {
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 2; ++i) rb[i] = lds_base + RC_T1A_OFF + ((pdy[i] + 2) * 22 + pdx[i] + 2) * RC_T1R + lhalf * 16;
         f32x16 acc[4];
-        chain_block<2, 22, S_B0, 2, true>(ring, y, rb, idf, ones, acc, ps, noside);
+        chain_block<2, 22, S_B0, 2, true>(ring, y, rb, idf, ones, acc, ps, noside, t1side);
         const unsigned a0 = lds_base + RC_T1B_OFF + ((pdy[0] + 2) * 20 + pdx[0] + 2) * RC_T1R + 8 * lhalf;
         const unsigned a1 = used1 ? lds_base + RC_T1B_OFF + ((pdy[1] + 2) * 20 + pdx[1] + 2) * RC_T1R + 8 * lhalf : 0xffffffffu;
         const unsigned m1 = inframe(pdy[1], pdx[1]);
@@ -539,14 +551,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned a0 = lds_base + RC_T1A_OFF + ((pdy[0] + 1) * 18 + pdx[0] + 1) * RC_T1R + 8 * lhalf;
         if (wave < 2) {
             f32x16 acc[4];
-            chain_block<2, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, ps, noside);
+            chain_block<2, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, ps, noside, noside);
             const unsigned a1 = used1 ? lds_base + RC_T1A_OFF + ((pdy[1] + 1) * 18 + pdx[1] + 1) * RC_T1R + 8 * lhalf : 0xffffffffu;
             const unsigned m1 = inframe(pdy[1], pdx[1]);
             store_t1(acc[0], a0, 0xffffffffu, 0); store_t1(acc[1], a0, 0xffffffffu, 1);
             store_t1(acc[2], a1, m1, 0); store_t1(acc[3], a1, m1, 1);
         } else {
             f32x16 acc[2];
-            chain_block<1, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, ps, noside);
+            chain_block<1, 20, S_B1, 2, false>(ring, y, rb, idf, ones, acc, ps, noside, noside);
             store_t1(acc[0], a0, 0xffffffffu, 0); store_t1(acc[1], a0, 0xffffffffu, 1);
         }
         lds_wait();
@@ -577,22 +589,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (mine) *reinterpret_cast<u32x4*>(YO + 32 * m + 16) = yhi;
             }
         };
-        chain_block<1, 18, S_B2, 4, false>(ring, y, rb, idf, ones, acc, ps, y2side);
+        chain_block<1, 18, S_B2, 4, false>(ring, y, rb, idf, ones, acc, ps, y2side, noside);
         ring.finish_tile();
         // everything this wave has in flight lands: the phantom groups behind the last one (or the next tile's first groups and p halo), y2
         wait_vmcnt<0>();
         stamp(5);
-        // t1out: 128 channels of the lane's pixel
-        bf16_t* T1O = static_cast<bf16_t*>(p.t1out) + ((size_t)b * 64 * 64 + (size_t)(y0 + pdy[0]) * 64 + x0 + pdx[0]) * 128 + 8 * lhalf;
+        // t1out: 128 channels of the lane's pixel, packed now, stored under the next tile's block 0 (t1side)
+        pend_ptr = static_cast<bf16_t*>(p.t1out) + ((size_t)b * 64 * 64 + (size_t)(y0 + pdy[0]) * 64 + x0 + pdx[0]) * 128 + 8 * lhalf;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             unsigned q[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) q[i] = relu2_bf16(acc[m][2 * i], acc[m][2 * i + 1]);
-            u32x4 lo, hi;
-            tile_to_rows(q, lo, hi);
-            *reinterpret_cast<u32x4*>(T1O + 32 * m) = lo;
-            *reinterpret_cast<u32x4*>(T1O + 32 * m + 16) = hi;
+            tile_to_rows(q, pend[2 * m], pend[2 * m + 1]);
+        }
+        if (k + 1 == nk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(pend_ptr + 32 * (j >> 1) + 16 * (j & 1)) = pend[j];
         }
     }
     if (p.ts && k == kstamp) {
