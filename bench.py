@@ -582,21 +582,17 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     else:
         cap = CapturedDqnStep(agent, replay, B, fused=fused, draw_seed=None if os.environ.get("IVOSW_BENCH_HOST_DRAW") else seed)
     nrep = len(replay)
-    # N > 1: the step is timed once per collective path.  "backend" = torch.distributed's all-reduce (RCCL over xGMI; gloo staged
-    # through the host in the one-GPU tests) followed by the fused clamp + Adam kernel: the product default.  "p2p" = the one-shot
-    # peer-to-peer all-reduce fused with clamp + Adam (two launches), opt-in in the product (IVOSW_P2P=1) because its cross-GPU path
-    # has never run outside this benchmark: it is attempted here (collective self-test against the backend's result) when
-    # IVOSW_BENCH_P2P=1, and timed only if every rank passed.  dqn.value is the faster VALIDATED path; the timed paths are in dqn.collectives.
-    legs = ["backend"] if FORCE_DIST[0] else [None]
-    if world > 1:
-        # the P2P leg is opt-in (IVOSW_BENCH_P2P=1): its cross-GPU path (IPC-mapped peer arenas, system-scope flags) has only ever run
-        # between two processes on ONE device, and a fault there would take the whole N > 1 record down with it
-        # round 6: attempted by DEFAULT, as a guarded LATE phase behind the backend leg - an 8-GPU node may run this
-        # build exactly once, and that one run has to answer both questions.  The set-up is collective and self-tested against the
-        # backend's result, a peer timeout raises on every rank, every failure lands in dqn.collectives.p2p.error and leaves the line
-        # intact; IVOSW_BENCH_P2P=0 (or IVOSW_P2P=0) skips the leg.
-        want_p2p = os.environ.get("IVOSW_BENCH_P2P", "1") != "0" and os.environ.get("IVOSW_P2P", "") != "0" and dev.type == "cuda"
-        legs = ["backend"] + (["p2p"] if want_p2p else [])
+    # N > 1: the step is timed through the backend's collective: torch.distributed's all-reduce (RCCL over xGMI; gloo staged through the
+    # host in the one-GPU tests) followed by the fused clamp + Adam kernel.  That is the product default and it is dqn.value.
+    # The one-shot peer-to-peer all-reduce fused with clamp + Adam (two launches; opt-in in the product, IVOSW_P2P=1) is attempted by
+    # DEFAULT too (an 8-GPU node may run this build exactly once, and that one run has to answer both questions),
+    # but as the LAST thing main() does, after every other number of the line exists (info["_p2p_leg"] below): its cross-GPU path
+    # (IPC-mapped peer arenas, system-scope flags) has only ever run between two processes on ONE device.  The set-up is collective
+    # and self-tested against the backend's result, a peer timeout raises on every rank, every failure lands in
+    # dqn.collectives.p2p.error, and a process that DIES in that leg still leaves the line behind (LineGuard).  IVOSW_BENCH_P2P=0
+    # (or IVOSW_P2P=0) skips the leg.
+    legs = ["backend"] if (FORCE_DIST[0] or world > 1) else [None]
+    want_p2p = world > 1 and os.environ.get("IVOSW_BENCH_P2P", "1") != "0" and os.environ.get("IVOSW_P2P", "") != "0" and dev.type == "cuda"
 
     def select_leg(name):
         if name is None:
@@ -624,7 +620,7 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
         if np.random.random() < agent.update_rate:
             agent.sync_target()
     loop, launch_mode = None, None
-    leg_us, p2p = {}, None
+    leg_us = {}
     if cap is not None and fused and cap.draw is not None and args.dqn_block > 1:
         # N = 1: the same steps in blocks of `dqn_block` per hipGraphLaunch whenever no target-sync coin of the block fires
         # (GraphedDqnLoop: same coin stream, same minibatch stream, bit-identical results; an 8.7 us bubble separates two
@@ -654,42 +650,40 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
     else:
         dt = None
         for leg in legs:
-            try:
-                h = select_leg(leg)
-            except Exception as e:                      # the P2P set-up is collective and guarded; a failure here leaves the backend leg's number
-                leg_us[leg] = {"error": repr(e)[:200]}
-                continue
-            if leg == "p2p" and h is None:
-                leg_us[leg] = {"skipped": "the self-test did not pass on every rank (or fine-grained / IPC memory is unavailable)"}
-                continue
-            n_leg = steps
-            if leg == "p2p":
-                # a path that has never run across GPUs must not be able to cost the line: short timeout, frequent error checks, fewer
-                # steps; a peer timeout raises on every rank within a few steps (the ranks that did arrive time out on the missing one),
-                # every rank lands in the handler below and the barrier re-aligns them; the backend leg's number stands
-                h.timeout_ms, n_leg = 250, min(steps, 500)
-            try:
-                d = timed(step, n_leg, warmup, dev, dist, min(args.min_warm_s, 0.5))
-                if h is not None:
-                    torch.cuda.synchronize(dev)
-                    if h.error() != 0:
-                        raise RuntimeError("the peer-to-peer all-reduce timed out waiting for a rank")
-            except RuntimeError as e:
-                if leg != "p2p":
-                    raise
-                leg_us[leg] = {"error": str(e)[:200]}
-                torch.cuda.synchronize(dev)
-                dist.barrier()
-                continue
-            if leg is not None:
-                leg_us[leg] = {"us_per_step": round(d / n_leg * 1e6, 1), "steps_per_sec_all_ranks": round(world * n_leg / d, 1), "steps": n_leg}
-                if leg == "backend":          # what actually carried the gradients: the process group's own answers, not this script's flags
-                    leg_us[leg].update(world_size=int(dist.get_world_size()), backend=str(dist.get_backend()))
-            d = d * steps / n_leg                   # per-step time scaled to the leg-independent step count used below
-            if dt is None or d < dt:
-                dt, p2p = d, h
-        if world > 1 and os.environ.get("IVOSW_P2P") is not None:
-            os.environ["IVOSW_P2P"] = "1" if p2p is not None else "0"
+            select_leg(leg)
+            dt = timed(step, steps, warmup, dev, dist, min(args.min_warm_s, 0.5))
+            if leg is not None:           # what actually carried the gradients: the process group's own answers, not this script's flags
+                leg_us[leg] = {"us_per_step": round(dt / steps * 1e6, 1), "steps_per_sec_all_ranks": round(world * steps / dt, 1), "steps": steps,
+                               "world_size": int(dist.get_world_size()), "backend": str(dist.get_backend())}
+
+    def p2p_leg():
+        """The guarded late leg (collective: every rank calls it).  Returns the dqn.collectives.p2p record."""
+        n_leg = min(steps, 500)
+        try:
+            h = select_leg("p2p")
+        except Exception as e:                          # the set-up is collective; a failure here is the same on every rank
+            return {"error": repr(e)[:200]}
+        if h is None:
+            return {"skipped": "the self-test did not pass on every rank (or fine-grained / IPC memory is unavailable)"}
+        # a path that has never run across GPUs: short timeout, frequent error checks, fewer steps; a peer timeout raises on every rank
+        # within a few steps (the ranks that did arrive time out on the missing one) and the barrier re-aligns them
+        h.timeout_ms = 250
+        try:
+            d = timed(step, n_leg, warmup, dev, dist, min(args.min_warm_s, 0.5))
+            torch.cuda.synchronize(dev)
+            if h.error() != 0:
+                raise RuntimeError("the peer-to-peer all-reduce timed out waiting for a rank")
+        except RuntimeError as e:
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            return {"error": str(e)[:200]}
+        finally:
+            os.environ["IVOSW_P2P"] = "0"
+        us = d / n_leg * 1e6
+        return {"us_per_step": round(us, 1), "steps_per_sec_all_ranks": round(world * n_leg / d, 1), "steps": n_leg,
+                "path": "one-shot xGMI peer-to-peer all-reduce fused with clamp + Adam (ivosw_p2p_allreduce_clamp_adam, self-tested against the backend's result at start-up)",
+                "vs_backend": round(leg_us["backend"]["us_per_step"] / us, 3),
+                "scaling_vs_1gpu": round(world * n_leg / d / DQN_1GPU_REF["steps_per_sec"], 3)}
     assert torch.isfinite(agent.policy_net.flat).all() and agent.optimizer.state["step"] >= steps + warmup
     sps = world * steps / dt
     per_gpu_tflops = DQN_GFLOP_PER_STEP * 1e9 * (sps / world) / 1e12
@@ -698,9 +692,9 @@ def bench_dqn(args, rank, world, dev, dist, steps, warmup):
             "scaling_vs_1gpu": {"value": round(sps / DQN_1GPU_REF["steps_per_sec"], 3), "n_gpus": world, "reference": DQN_1GPU_REF} if world > 1 or FORCE_DIST[0] else None,
             "launch_mode": launch_mode,
             "step_structure": "data-parallel: gradients -> collective -> clamp + Adam" + (" (emulated at N = 1, no collective)" if world == 1 and not FORCE_DIST[0] else " (forced at N = 1: the collective runs over one rank)" if world == 1 else "") if dp else "single GPU: fused step",
-            "collective_path": (("one-shot xGMI peer-to-peer all-reduce fused with clamp + Adam (ivosw_p2p_allreduce_clamp_adam, self-tested against the backend's result at start-up)" if p2p is not None
-                                 else "RCCL all-reduce" if BACKEND[0] == "nccl" else "gloo all-reduce staged through host memory") if world > 1 or FORCE_DIST[0] else None),
+            "collective_path": (("RCCL all-reduce" if BACKEND[0] == "nccl" else "gloo all-reduce staged through host memory") if world > 1 or FORCE_DIST[0] else None),
             "collectives": (leg_us if (world > 1 or FORCE_DIST[0]) and launch_mode is None else None),
+            "_p2p_leg": p2p_leg if want_p2p and launch_mode is None else None,        # run by main() as its last act; never serialised
             "kernel_nodes_in_graph": cap.kernel_nodes if cap is not None else None,
             "host_launches_per_step": (round(launches_per_step, 3) if launch_mode is not None else (1 if fused else 3) + (cap.draw is None)) if cap is not None else None,
             "steps_per_graph_launch": args.dqn_block if loop is not None else (1 if cap is not None else None),
@@ -950,6 +944,37 @@ def cpu_baseline_dqn():
                       f"best of several thread counts"}
 
 
+class LineGuard:
+    """Keeps the JSON line alive across a leg that may take the process down.  A child process holds the finished line (with
+    collectives.p2p = the failure note) and the read end of a pipe; it prints the line to the inherited stdout iff the pipe closes
+    without the one byte disarm() sends.  Works for any death of the parent (abort() inside the HIP runtime, SIGKILL from the launcher)."""
+    CHILD = ("import sys,os\n"
+             "fd=int(sys.argv[1]); line=sys.stdin.buffer.read(); sys.stdin.close()\n"
+             "b=os.read(fd,1)\n"
+             "if not b: sys.stdout.buffer.write(line+b'\\n'); sys.stdout.flush()\n")
+
+    def __init__(self, line, rec):
+        import subprocess
+        saved = rec.get("p2p")
+        rec["p2p"] = {"error": "the process died inside the peer-to-peer leg (hard fault); every other number of this line was measured before it started; "
+                               "line printed by the watchdog child"}
+        payload = json.dumps(line).encode()
+        if saved is None:
+            rec.pop("p2p")
+        else:
+            rec["p2p"] = saved
+        r, self.w = os.pipe()
+        self.child = subprocess.Popen([sys.executable, "-c", self.CHILD, str(r)], stdin=subprocess.PIPE, pass_fds=(r,), close_fds=True)
+        os.close(r)
+        self.child.stdin.write(payload)
+        self.child.stdin.close()
+
+    def disarm(self):
+        os.write(self.w, b"k")
+        os.close(self.w)
+        self.child.wait(timeout=10)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1063,6 +1088,16 @@ def main():
                 dt_live = dqn_live_traffic()
                 if dt_live is not None:
                     line["dqn"]["roofline"].update(dt_live)
+    late_p2p = (line["dqn"] if args.workload == "assess" else line).pop("_p2p_leg", None)
+    if late_p2p is not None:
+        # every other number of the line exists now.  Rank 0 hands the line to a watchdog child before the leg starts: if this process
+        # dies in it (a GPU fault aborts the process from inside the HIP runtime, where no Python handler runs), the child prints the
+        # line with the failure recorded; otherwise the leg's record goes into the line and this process prints it as usual.
+        rec = (line["dqn"] if args.workload == "assess" else line)["collectives"]
+        guard = LineGuard(line, rec) if rank == 0 else None
+        rec["p2p"] = late_p2p()
+        if guard is not None:
+            guard.disarm()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

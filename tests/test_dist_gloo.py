@@ -142,3 +142,37 @@ def test_forced_world_of_one_goes_through_the_backend_collective():
     assert q.get(timeout=120) == "ok"
     p.join(60)
     assert p.exitcode == 0
+
+
+@pytest.mark.parametrize("die", [False, True])
+def test_bench_line_survives_a_process_that_dies_in_the_late_p2p_leg(die):
+    """bench.py runs the peer-to-peer DQN leg as its LAST act under LineGuard: a watchdog child that holds the finished line and prints it
+    iff the parent dies before disarming (abort() from inside the HIP runtime runs no Python handler).  Exactly one line either way."""
+    import json
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f'''
+        import importlib.util, json, os, sys
+        sys.argv = ["bench.py"]
+        spec = importlib.util.spec_from_file_location("bench", {os.path.join(root, "bench.py")!r})
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        line = {{"metric": "assessed_frames_per_sec", "value": 1.0, "dqn": {{"collectives": {{"backend": {{"us_per_step": 200.0}}}}}}}}
+        g = b.LineGuard(line, line["dqn"]["collectives"])
+        assert "p2p" not in line["dqn"]["collectives"]
+        if {die!r}:
+            os.abort()
+        line["dqn"]["collectives"]["p2p"] = {{"us_per_step": 150.0}}
+        g.disarm()
+        print(json.dumps(line), flush=True)
+    ''')
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-500:])
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and d["dqn"]["collectives"]["backend"]["us_per_step"] == 200.0
+    if die:
+        assert r.returncode != 0 and "died inside the peer-to-peer leg" in d["dqn"]["collectives"]["p2p"]["error"]
+    else:
+        assert r.returncode == 0 and d["dqn"]["collectives"]["p2p"] == {"us_per_step": 150.0}
