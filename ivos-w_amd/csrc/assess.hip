@@ -318,7 +318,7 @@ extern "C" size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chun
 extern "C" int ivosw_assess_split(int dtype, int B, int chunk) { return split_wanted(dtype, B, chunk, 0) ? 1 : 0; }
 
 extern "C" const char* ivosw_assess_dominant_kernel(int dtype) {
-    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|res2_chain_kernel*|gemm_8phase*|stage_first*|stem_pool*" : "conv_igemm*";   // the tower's contraction kernels (one family)
+    return dtype == IVOSW_BF16 ? "conv_igemm*|conv1x1_wide*|conv3x3_patch*|bneck*|res2_stage*|res2_chain_kernel*|gemm_8phase*|stage_first*|stem_pool*" : dtype == IVOSW_F32X3 ? "conv_igemm*|stem_pool_x3*" : "conv_igemm*";   // the tower's contraction kernels (one family)
 }
 
 static int assess_forward_impl(const void* packed, int dtype, const float* tf, const float* tp, const SampleMap& sm, int B, int H, int W,
@@ -675,6 +675,9 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                     if (dtype == IVOSW_BF16 && tap_stage != 2 && tune_get("FUSE_STEM", 1)) {
                         dir = 1;                 // every res2 chunk starts the alternation anew at its stem
                         launch_stem_pool(bf.roi, base + P.stem_w_off, reinterpret_cast<const float*>(base + P.stem_b_off), nb, bf.pa, st, next_dir());
+                    } else if (dtype == IVOSW_F32X3 && tap_stage != 2 && tune_get("FUSE_STEM_X3", 1)) {
+                        // the three-pass mode's stem + pool as one launch (stem.hip): fp32 ROI tile in, split pooled map out
+                        launch_stem_pool_x3(bf.roi, base + P.stem_w_off, reinterpret_cast<const float*>(base + P.stem_b_off), nb, bf.pa, st, 0);
                     } else {
                         ConvArgs a{};
                         a.zeros = base + P.zero_off; a.x = bf.roi; a.w = base + P.stem_w_off; a.bias = reinterpret_cast<const float*>(base + P.stem_b_off);

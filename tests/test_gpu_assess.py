@@ -149,6 +149,32 @@ def test_bf16x3_mode_meets_the_fp32_bars_against_the_reference_goldens(dev, gold
     print(f"bf16x3 worst relative score error vs reference: {max(worst, float(np.max(np.abs(s - ref) / np.abs(ref)))):.2e}")
 
 
+def test_bf16x3_fused_stem_and_pool_equals_the_two_launches(dev):
+    """stem_pool_x3_kernel (stem.hip, round 6: the three-pass mode's 7x7/2 conv + BN + ReLU + 3x3/2 max-pool as ONE launch - the patch split
+    once per pixel, the pre-split filter bank in LDS, the conv tile pooled out of LDS) against the layer path it replaces (generic implicit-GEMM
+    conv on the fp32 ROI tile, split map to HBM, maxpool_x3_kernel; tunable FUSE_STEM_X3 = 0): same split arithmetic, same MFMA order per
+    k-step - the pooled map and everything behind it are bit-identical, on edge masks
+    (ROI tiles with zero borders), a single frame and a batch that spans several 64-tile rounds of a workgroup."""
+    from ivos_w_amd import _lib as L
+    nx = make_net(dev, "bf16x3")
+    for B, edge in ((8, True), (1, False), (5, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        out = {}
+        for mode in (1, 0):
+            L.tune_set(b"FUSE_STEM_X3", mode)
+            try:
+                _, pool = nx.forward_tap(ttf, ttp, "pool")
+                out[mode] = (pool.cpu().numpy(), nx(ttf, ttp).cpu().numpy())
+            finally:
+                L.tune_set(b"FUSE_STEM_X3", 1)
+        a, b = out[1][0], out[0][0]
+        assert a.shape == b.shape == (B, 64, 64, 64) and np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+        assert (a > 0).mean() > 0.2                                  # a live map, not zeros against zeros
+        np.testing.assert_array_equal(out[1][1], out[0][1])
+        print(f"x3 fused stem, B={B}: pooled map max abs diff {np.abs(a - b).max():.2e}, bit-identical {bool(np.array_equal(a, b))}")
+
+
 def test_fp32_b3_and_chunking(dev, gold):
     _, _, ttf, ttp = inputs(dev, 3, False)
     net = make_net(dev, "fp32", chunk=2)                  # ragged last chunk
