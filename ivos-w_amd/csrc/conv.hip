@@ -94,8 +94,10 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
             const int c = (n & 31) >> 3;
             const uint4* rs = reinterpret_cast<const uint4*>(R + og);
             if (R) {
-                const uint4 rh = rs[c], rl = rs[4 + c];
-                const uint32_t h4[4] = {rh.x, rh.y, rh.z, rh.w}, l4[4] = {rl.x, rl.y, rl.z, rl.w};
+                u32x4 rh, rl;
+                if (p.nt & 8) { rh = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rs + c)); rl = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rs + 4 + c)); }
+                else { rh = *reinterpret_cast<const u32x4*>(rs + c); rl = *reinterpret_cast<const u32x4*>(rs + 4 + c); }
+                const uint32_t h4[4] = {rh[0], rh[1], rh[2], rh[3]}, l4[4] = {rl[0], rl[1], rl[2], rl[3]};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[2 * q] += __uint_as_float(h4[q] << 16) + __uint_as_float(l4[q] << 16);
@@ -109,8 +111,14 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
             uint32_t hi[4], lo[4];
             split8_store_x3(v, hi, lo);
             uint4* ys = reinterpret_cast<uint4*>(Y + og);
-            ys[c] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-            ys[4 + c] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            if (p.nt & 4) {
+                const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+                __builtin_nontemporal_store(vh, reinterpret_cast<u32x4*>(ys + c));
+                __builtin_nontemporal_store(vl, reinterpret_cast<u32x4*>(ys + 4 + c));
+            } else {
+                ys[c] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                ys[4 + c] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+            }
         } else {
             if (R) {
                 const float4 r0v = *reinterpret_cast<const float4*>(R + o);
@@ -1100,6 +1108,9 @@ void launch_conv(const ConvArgs& a_in, int dtype, bool stem, hipStream_t st) {
         const int nm = tune_get("NMAJOR", 0);       // 0 off, 1 all ws / patch launches, 2 only 3x3
         a.nmajor = (nm == 1) || (nm == 2 && a.KH == 3);
         a.nt = tune_get("NT", 3);   // streaming tensors are far larger than L2: keep them from evicting the A / weight lines that ARE reused
+        // three-pass mode: bit 2 / 3 = non-temporal stores / residual loads of the split activations (NT_X3 = 1 / 2 / 3).  Two alternating rounds
+        // of the whole mode on one box: stores + 1.5 % (20.97 -> 21.28 k frames/s), residual loads - 0.3 %, both + 1.1 %: stores only
+        if (dtype == IVOSW_F32X3) a.nt |= tune_get("NT_X3", 1) << 2;
     }
     a.x3 = dtype == IVOSW_F32X3 ? 2 : 0;         // 2: activations in the split layout (every output; every input except the stem's ROI tile)
     void* tok = prof_begin(a, (dtype == IVOSW_BF16) ? 2 : 4, st);
