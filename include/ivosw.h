@@ -177,7 +177,7 @@ int ivosw_assess_pack(void* packed, int dtype, const void* const* tensors, int n
                       ivosw_stream_t stream);
 /* Replaces AssessNet.forward (models/assessment.py:164-182): tf [B,3,H,W], tp [B,H,W] fp32 ->
  * scores [B] fp32.  Frames are processed in chunks of `chunk` frames at res2, doubling per stage
- * (<=0: library default, 256 bf16 / 64 fp32); the chunk bounds the workspace (ivosw_assess_ws_bytes).
+ * (<=0: library default, 256 bf16 / 128 fp32 modes); the chunk bounds the workspace (ivosw_assess_ws_bytes).
  * tap_stage/tap_out (debug, tests): 0 = none; 1 roi[.,256,256,4] 2 stem[.,128,128,64] 3 pool[.,64,64,64]
  * 4..7 res2..res5 outputs, NHWC in `dtype`; 8 pooled [.,2048] fp32.  Only with B <= chunk.        */
 size_t ivosw_assess_ws_bytes(int dtype, int B, int H, int W, int chunk);

@@ -143,7 +143,9 @@ constexpr size_t E_OUT[4] = {64 * 64 * 256, 32 * 32 * 512, 16 * 16 * 1024, 8 * 8
 // Chunk schedule.  Stage s (res2..res5) runs on c0 * 2^s frames at a time: every stage halves H and W and
 // doubles C, so doubling the frames per launch keeps the per-stage tensor size constant (c0 * 2 MB bf16) and every
 // conv launch keeps >= 512 workgroups for the 256 CUs.
-static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 256 : std::max(1, tune_get("F32_CHUNK", 64)); }   // fp32: 16 -> 64 frames per res2 launch = 6.8 k -> 9.9 k frames/s (128: 9.96 k at twice the workspace)
+// fp32 modes: 16 -> 64 frames per res2 launch = 6.8 k -> 9.9 k frames/s; 128 (round 6): fp32 9.96 k, the three-pass mode 21.32 -> 21.57 k (two alternating rounds), at
+// twice the workspace (11.5 instead of 5.75 GiB at batch 256 - of 288 GB)
+static int default_chunk(int dtype) { return dtype == IVOSW_BF16 ? 256 : std::max(1, tune_get("F32_CHUNK", 128)); }
 
 struct Bufs {
     float* yxhw; int32_t* box; float* pooled;
