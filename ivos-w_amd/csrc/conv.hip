@@ -959,6 +959,204 @@ __global__ __launch_bounds__(1024) void conv3x3_patch_kernel(ConvArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- the same for the three-pass mode's 64-channel 3x3 (res2, IVOSW_F32X3; round 6)
+// res2's 3x3 (64 -> 64 channels on 64 x 64 frames) was the largest row of that mode's layer table: 256 x 64 tiles of the per-tap kernel gather
+// 9 taps x 2 slices x 32 KB of pixels per tile - 734 KB with the weights - and sit on the CU's fill rate at 185 "fp32-equivalent" TFLOP/s where the
+// 128-channel 3x3 layers reach 314 - 335.  Here a workgroup owns a 16 x 16-pixel tile: its 18 x 18 halo patch is fetched once per 32-channel slice
+// (128-byte rows in the split layout [32 hi | 32 lo], 41 KB per slice), the nine taps read it through shifted rows, only the 8-KB weight tiles
+// stream per (slice, tap): 227 KB per tile.  Four compute waves own 2 pixel tiles x BOTH 32-channel tiles (16 KB of fragment reads per 24 MFMAs:
+// 83 B/clk of LDS reads per CU; eight waves with one channel tile each would need 125), four loader waves issue the LDS-DMA.
+// K order: slice-major (all nine taps of channels 0 .. 31, then 32 .. 63) - the per-tap kernel runs tap-major, so the two differ in the last
+// bits of the fp32 sums (not bit-identical; the test compares them at 1e-6).  LDS: two patch buffers | 3-slot weight ring; the epilogue tile aliases.
+__global__ __launch_bounds__(512) void conv3x3_patch_x3_kernel(ConvArgs p) {
+    constexpr int TH = 16, TW = 16, HW2 = TW + 2, HRT = (TH + 2) * HW2;        // 324 halo rows
+    constexpr int NG = (HRT + 7) / 8, PB = NG * 1024;                          // 41 DMA row groups, 41 984 B per slice
+    constexpr int BM = 256, BN = 64, NW = 4, LW = 4, TM = 2, TN = 2, KE = 32, CE = 4;   // floats per K-tile / per 16-byte chunk
+    constexpr int WSLOT = BN * ROWB, WR = 3, W_OFF = 2 * PB;
+    constexpr int EPI_BYTES = BM * BN * 4, USED = W_OFF + WR * WSLOT;
+    constexpr int LDS_BYTES = USED > EPI_BYTES ? USED : EPI_BYTES;
+    static_assert(LDS_BYTES <= 163840, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = p.rev ? (int)gridDim.x - 1 - L : L;
+    const int tpx = p.W / TW, tpf = (p.H / TH) * tpx;
+    const int b0 = tile_m / tpf, tl = tile_m - b0 * tpf;
+    const int y0 = (tl / tpx) * TH, x0 = (tl % tpx) * TW;
+    const int K = 9 * p.Cin;
+    const int nc = p.Cin / KE, nj = nc * 9;
+
+    if (wave >= NW) {
+        // ================= loader wave =================
+        const int lw = wave - NW;
+        const float* X = static_cast<const float*>(p.x);
+        const float* Wt = static_cast<const float*>(p.w);
+        const float* zeros = static_cast<const float*>(p.zeros);
+        const int rsub = lane >> 3, cpos = lane & 7;
+        constexpr int MAXG = (NG + LW - 1) / LW;             // 11
+        const int np = (NG - lw + LW - 1) / LW;
+        const float* abase[MAXG];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) {
+            const int g = lw + LW * i;
+            const int hr = g * 8 + rsub;
+            const int hy = hr / HW2, hx = hr - hy * HW2;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NG && hr < HRT && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            abase[i] = ok ? X + (((long)b0 * p.H + y) * p.W + x) * p.Cin + (cpos ^ patch_key<TW>(hy, hx)) * CE : zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        const float* bsrc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (lw * 2 + i) * 8 + rsub;
+            bsrc[i] = Wt + (long)row * K + (cpos ^ ((row >> 1) & 7)) * CE;
+        }
+        auto issue_patch = [&](int c) {
+            unsigned char* pbuf = lds + (c & 1) * PB;
+#pragma unroll
+            for (int i = 0; i < MAXG; ++i) {
+                const int g = lw + LW * i;
+                if (g < NG) dma16(abase[i] + (((okmask >> i) & 1u) ? c * KE : 0), pbuf + g * 1024);
+            }
+        };
+        auto issue_w = [&](int j) {                          // weight tile of step j = slice * 9 + tap
+            const int c = j / 9, t = j - c * 9;
+            unsigned char* sb = lds + W_OFF + (j % WR) * WSLOT;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) dma16(bsrc[i] + (long)t * p.Cin + c * KE, sb + (lw * 2 + i) * 1024);
+        };
+        // issue order: P0 W0 W1 | after barrier j: W(j+2); after barrier (c,3): P(c+1)        [as conv3x3_patch_kernel]
+        issue_patch(0);
+        issue_w(0);
+        issue_w(1);
+        for (int j = 0; j < nj; ++j) {
+            const int c = j / 9, t = j - c * 9;
+            int younger = (j + 1 < nj) ? 2 : 0;
+            if ((t == 4 || t == 5) && c + 1 < nc) younger += np;
+            wait_vmcnt_n(younger);
+            __builtin_amdgcn_s_barrier();
+            if (j + 2 < nj) issue_w(j + 2);
+            if (t == 3 && c + 1 < nc) issue_patch(c + 1);
+        }
+        __builtin_amdgcn_s_barrier();                        // matches the two epilogue barriers of the compute waves
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ================= compute wave: pixel tiles 2 wave, 2 wave + 1 (rows 4 wave .. 4 wave + 3 of the tile) x both channel tiles =================
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int hb[TM], hy0[TM], hx0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wave * TM + i) * 32 + lrow;
+        const int y = m / TW, x = m - y * TW;
+        hb[i] = y * HW2 + x;
+        hy0[i] = y; hx0[i] = x;
+    }
+    int c = 0, t = 0;
+    for (int j = 0; j < nj; ++j) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned a_base = lds_base + (c & 1) * PB, b_base = lds_base + W_OFF + (j % WR) * WSLOT;
+        const int ky = t / 3, kx = t - ky * 3;
+        unsigned arow[TM], asw[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            arow[i] = a_base + (hb[i] + ky * HW2 + kx) * ROWB;
+            asw[i] = patch_key<TW>(hy0[i] + ky, hx0[i] + kx);
+        }
+        u32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+        auto frag_read = [&](int s2, int buf) {              // ktile_mma_x3<PRE = true>'s chunks: hi at 2 s + h, lo at 4 + 2 s + h
+            const int ch = 2 * s2 + lhalf;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[buf][i] = lds_read_b128(arow[i] + ((ch ^ asw[i]) << 4));
+                al[buf][i] = lds_read_b128(arow[i] + (((4 + ch) ^ asw[i]) << 4));
+            }
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                bh[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, ch));
+                bl[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, 4 + ch));
+            }
+        };
+        frag_read(0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            lds_wait();
+            if (s2 < 1) frag_read(1, 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    acc[i][jj] = mfma_bf16(ah[s2][i], bh[s2][jj], acc[i][jj]);
+                    acc[i][jj] = mfma_bf16(ah[s2][i], bl[s2][jj], acc[i][jj]);
+                    acc[i][jj] = mfma_bf16(al[s2][i], bh[s2][jj], acc[i][jj]);
+                }
+        }
+        if (++t == 9) { t = 0; ++c; }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float* Cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wave * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const int col = j * 32 + lrow;
+                Cs[row * BN + col] = acc[i][j][r];
+            }
+    __syncthreads();                                         // the LDS-write drain + the second epilogue barrier (the loader waves count it too)
+    // store pass: thread = (tile pixel, 8 channels); + bias, ReLU, split (epilogue_store's IVOSW_F32X3 branch)
+    constexpr int CPR = BN / 8;
+    float* Y = static_cast<float*>(p.y);
+    const float4 bb0 = *reinterpret_cast<const float4*>(p.bias + (tid % CPR) * 8);
+    const float4 bb1 = *reinterpret_cast<const float4*>(p.bias + (tid % CPR) * 8 + 4);
+#pragma unroll
+    for (int it = 0; it < (BM * CPR) / (NW * 64); ++it) {
+        const int item = it * (NW * 64) + tid;
+        const int row = item / CPR, cg = item - row * CPR;
+        const int y = row / TW, x = row - y * TW;
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * BN + cg * 8 + 4);
+        float v[8] = {v0.x + bb0.x, v0.y + bb0.y, v0.z + bb0.z, v0.w + bb0.w, v1.x + bb1.x, v1.y + bb1.y, v1.z + bb1.z, v1.w + bb1.w};
+        if (p.relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+        uint32_t hi[4], lo[4];
+        split8_store_x3(v, hi, lo);
+        const int n = cg * 8;
+        uint4* ys = reinterpret_cast<uint4*>(Y + ((((long)b0 * p.H + y0 + y) * p.W + x0 + x)) * p.Cout + (n & ~31));
+        const int cq = (n & 31) >> 3;
+        if (p.nt & 4) {
+            const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+            __builtin_nontemporal_store(vh, reinterpret_cast<u32x4*>(ys + cq));
+            __builtin_nontemporal_store(vl, reinterpret_cast<u32x4*>(ys + 4 + cq));
+        } else {
+            ys[cq] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            ys[4 + cq] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    }
+}
+static bool patch3x3_x3_ok(const ConvArgs& a) {              // res2's 3x3 in the split activation format; the shape only, never the batch
+    return a.x3 == 2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.res && !a.x2 && a.Cin == 64 && a.Cout == 64 &&
+           a.H == a.W && a.H % 16 == 0 && a.Ho == a.H && a.Wo == a.W && a.zeros;
+}
+
 // shapes covered by conv3x3_patch_kernel
 static bool patch3x3_ok(const ConvArgs& a) {
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.res || a.H != a.W || a.Cin % 64 || a.Cout % 128) return false;
@@ -1023,6 +1221,12 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<T, 4, 2, 1, 2, 2, X3>), dim3(g2), dim3(512), 0, st, a);
             }
         } else {  // Cout == 64 layers: 256 x 64 tile
+            if constexpr (X3) {
+                if (patch3x3_x3_ok(a) && tune_get("PATCH3_X3", 1)) {
+                    hipLaunchKernelGGL(conv3x3_patch_x3_kernel, dim3(a.B * (a.H / 16) * (a.W / 16)), dim3(512), 0, st, a);
+                    return;
+                }
+            }
             const int grid = ((M + 255) / 256) * (a.Cout / 64);
             static const int use_ws64 = getenv("IVOSW_TUNE_WS") ? atoi(getenv("IVOSW_TUNE_WS")) : 1;
             if (nk >= 4 && use_ws64) hipLaunchKernelGGL((conv_igemm_ws_kernel<T, 4, 2, 2, 1, 3, 4, X3>), dim3(grid), dim3(768), 0, st, a);

@@ -175,6 +175,35 @@ def test_bf16x3_fused_stem_and_pool_equals_the_two_launches(dev):
         print(f"x3 fused stem, B={B}: pooled map max abs diff {np.abs(a - b).max():.2e}, bit-identical {bool(np.array_equal(a, b))}")
 
 
+def test_bf16x3_patch_kernel_of_res2_3x3_against_the_per_tap_kernel(dev, gold):
+    """conv3x3_patch_x3_kernel (conv.hip, round 6: res2's 64-channel 3x3 of the three-pass mode on 16 x 16-pixel tiles with an LDS-resident
+    18 x 18 halo patch per 32-channel slice, split layout in and out) against the per-tap implicit-GEMM kernel it replaces (tunable
+    PATCH3_X3 = 0).  Same products, another K order (slice-major against tap-major): res2 / res5 taps and scores agree to fp32 summation
+    noise (plus single flips of the split format's last bit), the reference goldens hold at the fp32 bars, on edge masks, a single frame and a ragged batch."""
+    from ivos_w_amd import _lib as L
+    nx = make_net(dev, "bf16x3")
+    for tag, B, edge in (("B8", 8, True), ("B1", 1, False), ("B5", 5, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        out = {}
+        for mode in (1, 0):
+            L.tune_set(b"PATCH3_X3", mode)
+            try:
+                _, r2 = nx.forward_tap(ttf, ttp, "res2")
+                out[mode] = (r2.cpu().numpy(), nx(ttf, ttp).cpu().numpy())
+            finally:
+                L.tune_set(b"PATCH3_X3", 1)
+        a, b = out[1][0], out[0][0]
+        assert a.shape == b.shape and np.isfinite(a).all() and (a > 0).mean() > 0.1
+        scale = np.abs(b).max()
+        # the split format keeps 16 mantissa bits per value: a last-bit difference of an fp32 sum can flip the lo half's rounding, i.e. one unit of
+        # 2^-16 of the value - the worst element may differ by that much, the mean difference stays at fp32 summation noise
+        assert np.abs(a - b).max() <= 3 * 2.0 ** -16 * scale and np.abs(a - b).mean() <= 1e-6 * scale, (np.abs(a - b).max(), np.abs(a - b).mean(), scale)
+        np.testing.assert_allclose(out[1][1], out[0][1], rtol=5e-6)
+        if tag in ("B8", "B1"):
+            np.testing.assert_allclose(out[1][1], gold[f"{tag}_score"], rtol=1e-4)
+        print(f"x3 patch 3x3, B={B}: res2 max abs diff {np.abs(a - b).max():.2e} of {scale:.2e}; scores max rel diff {np.abs(out[1][1] / out[0][1] - 1).max():.2e}")
+
+
 def test_fp32_b3_and_chunking(dev, gold):
     _, _, ttf, ttp = inputs(dev, 3, False)
     net = make_net(dev, "fp32", chunk=2)                  # ragged last chunk
