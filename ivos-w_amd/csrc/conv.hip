@@ -50,6 +50,25 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
     // the thread's 8 output channels are the same for all of its items: one bias fetch
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + (tid % CPR) * 8);
     const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + (tid % CPR) * 8 + 4);
+    // IVOSW_F32X3 residual: ALL items' (hi, lo) chunks are requested before the first item is processed (round 6).  Inside the item loop a
+    // load sits behind the previous item's stores, which the compiler must assume may alias: a chain of ITEMS dependent round trips per thread
+    constexpr int XIT = (ES == 4) ? (BM * CPR) / NT : 1;
+    u32x4 xrh[XIT], xrl[XIT];
+    const bool xres = ES == 4 && p.x3 == 2 && R != nullptr && !ABL(p.debug, 1);
+    if constexpr (ES == 4) {
+        if (xres) {
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) {
+                const int item = it * NT + tid;
+                const int row = item / CPR, cg = item - row * CPR;
+                const int m = min(m0 + row, M - 1);
+                const int n = n0 + cg * 8;
+                const u32x4* rs = reinterpret_cast<const u32x4*>(R + (long)m * p.Cout + (n & ~31));
+                if (p.nt & 8) { xrh[it] = __builtin_nontemporal_load(rs + ((n & 31) >> 3)); xrl[it] = __builtin_nontemporal_load(rs + 4 + ((n & 31) >> 3)); }
+                else { xrh[it] = rs[(n & 31) >> 3]; xrl[it] = rs[4 + ((n & 31) >> 3)]; }
+            }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < (BM * CPR) / NT; ++it) {
         const int item = it * NT + tid;
@@ -94,9 +113,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
             const int c = (n & 31) >> 3;
             const uint4* rs = reinterpret_cast<const uint4*>(R + og);
             if (R) {
-                u32x4 rh, rl;
-                if (p.nt & 8) { rh = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rs + c)); rl = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rs + 4 + c)); }
-                else { rh = *reinterpret_cast<const u32x4*>(rs + c); rl = *reinterpret_cast<const u32x4*>(rs + 4 + c); }
+                const u32x4 rh = xrh[ES == 4 ? it : 0], rl = xrl[ES == 4 ? it : 0];
                 const uint32_t h4[4] = {rh[0], rh[1], rh[2], rh[3]}, l4[4] = {rl[0], rl[1], rl[2], rl[3]};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
