@@ -54,7 +54,7 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
     // load sits behind the previous item's stores, which the compiler must assume may alias: a chain of ITEMS dependent round trips per thread
     constexpr int XIT = (ES == 4) ? (BM * CPR) / NT : 1;
     u32x4 xrh[XIT], xrl[XIT];
-    const bool xres = ES == 4 && p.x3 == 2 && R != nullptr && !ABL(p.debug, 1);
+    const bool xres = ES == 4 && R != nullptr && !ABL(p.debug, 1);              // (plain fp32 tensors too: the item's two float4)
     if constexpr (ES == 4) {
         if (xres) {
 #pragma unroll
@@ -63,6 +63,11 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
                 const int row = item / CPR, cg = item - row * CPR;
                 const int m = min(m0 + row, M - 1);
                 const int n = n0 + cg * 8;
+                if (p.x3 != 2) {
+                    const u32x4* rf = reinterpret_cast<const u32x4*>(R + (long)m * p.Cout + n);
+                    xrh[it] = rf[0]; xrl[it] = rf[1];
+                    continue;
+                }
                 const u32x4* rs = reinterpret_cast<const u32x4*>(R + (long)m * p.Cout + (n & ~31));
                 if (p.nt & 8) { xrh[it] = __builtin_nontemporal_load(rs + ((n & 31) >> 3)); xrl[it] = __builtin_nontemporal_load(rs + 4 + ((n & 31) >> 3)); }
                 else { xrh[it] = rs[(n & 31) >> 3]; xrl[it] = rs[4 + ((n & 31) >> 3)]; }
@@ -138,10 +143,9 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& p, const float* C
             }
         } else {
             if (R) {
-                const float4 r0v = *reinterpret_cast<const float4*>(R + o);
-                const float4 r1v = *reinterpret_cast<const float4*>(R + o + 4);
-                v[0] += r0v.x; v[1] += r0v.y; v[2] += r0v.z; v[3] += r0v.w;
-                v[4] += r1v.x; v[5] += r1v.y; v[6] += r1v.z; v[7] += r1v.w;
+                const u32x4 r0v = xrh[ES == 4 ? it : 0], r1v = xrl[ES == 4 ? it : 0];
+                v[0] += __uint_as_float(r0v[0]); v[1] += __uint_as_float(r0v[1]); v[2] += __uint_as_float(r0v[2]); v[3] += __uint_as_float(r0v[3]);
+                v[4] += __uint_as_float(r1v[0]); v[5] += __uint_as_float(r1v[1]); v[6] += __uint_as_float(r1v[2]); v[7] += __uint_as_float(r1v[3]);
             }
             if (p.relu) {
 #pragma unroll
