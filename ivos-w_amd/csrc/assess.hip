@@ -629,6 +629,14 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 }
             }
             if (!(s == 1 && b == 0 && fwd2)) mk(c1, x, hw, hw, nullptr, bf.m1, 1);     // forwarded: res2's last block wrote it
+            if (dtype == IVOSW_F32X3 && s == 0 && bp.ds < 0 && hw == 64 && c2.K == 3 && c2.stride == 1 && c2.Cin == 64 && c2.Cout == 64 && c3.Cin == 64 &&
+                c3.Cout == 256 && tune_get("FUSE_TAIL_X3", 1)) {
+                // the three-pass mode's identity blocks of res2 behind their conv1: 3x3 -> conv3 + residual as one launch (conv.hip: t2 stays on the CU)
+                launch_res2_tail_x3(bf.m1, x, base + c2.w_off, reinterpret_cast<const float*>(base + c2.b_off), base + c3.w_off,
+                                    reinterpret_cast<const float*>(base + c3.b_off), base + P.zero_off, y, nb, hw, hw, next_dir(), st);
+                x = y;
+                continue;
+            }
             mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
             const void* idt = x;
             if (bp.ds >= 0 && tune_get("FUSE_DS", 1)) {

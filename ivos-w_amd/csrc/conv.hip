@@ -1173,6 +1173,308 @@ __global__ __launch_bounds__(512) void conv3x3_patch_x3_kernel(ConvArgs p) {
         }
     }
 }
+// ---------------------------------------------------------------- res2's identity blocks of the three-pass mode behind their conv1: 3x3 -> conv3 + residual in ONE launch
+// (round 6).  Layer by layer the 64-channel t2 (1 KB per pixel in the split format, written and read back) and a second launch's prologue sit
+// between the patch kernel above and the 64 -> 256 expand layer, which is bound by its 4-byte tensors (t2 in, residual in, y out).  Here the
+// patch kernel's accumulators become the expand layer's pixel operand without leaving the CU: t2 = relu(acc + b2) goes to LDS, is split IN
+// PLACE (a 32-channel group of the split format is the 128 bytes of its 32 floats; the eight lanes that own a row read before any of them
+// writes), and four 64-channel chunks of y = relu(W3 t2 + b3 + x) follow, their weight tiles (8 KB per chunk and 32-channel K-tile) through
+// the same ring behind the eighteen 3x3 tiles.  Every row of t2 / of a y chunk belongs to ONE compute wave (pixel tiles 2 w, 2 w + 1) from
+// the accumulators to the store pass, so phase 2 needs no barrier beyond the ring's.  Per pixel the products and their order are those of the
+// two kernels it replaces (conv3x3_patch_x3_kernel, then the 128 x 128-tile expand layer: K-tile order, hi/lo order, bias after the sum,
+// residual after the bias): bit-identical to them.
+// LDS (152 KB): ring [0, 24 K) | patch buffers [24 K, 106 K) -> t2 [24 K, 88 K) | y-chunk staging [88 K, 152 K).
+struct Res2TailX3Args {
+    const float *t1, *x, *w2, *b2, *w3, *b3, *zeros;
+    float* y;
+    int B, H, W, nt, rev;
+};
+__global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
+    constexpr int TH = 16, TW = 16, HW2 = TW + 2, HRT = (TH + 2) * HW2, NG = (HRT + 7) / 8, PB = NG * 1024;
+    constexpr int NW = 4, LW = 4, TM = 2, TN = 2, KE = 32, CE = 4, C = 64, C4 = 256;
+    constexpr int WSLOT = 64 * ROWB, WR = 3, P_OFF = WR * WSLOT, T2_OFF = P_OFF, YC_OFF = T2_OFF + 256 * 256;
+    constexpr int LDS_BYTES = YC_OFF + 256 * 256;
+    constexpr int NJ1 = 18, NJ = NJ1 + 8;                    // ring tiles: (slice, tap) of the 3x3, then (chunk, K-tile) of the expand layer
+    static_assert(P_OFF + 2 * PB <= LDS_BYTES && LDS_BYTES <= 163840, "LDS map");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = p.rev ? (int)gridDim.x - 1 - L : L;
+    const int tpx = p.W / TW, tpf = (p.H / TH) * tpx;
+    const int b0 = tile_m / tpf, tl = tile_m - b0 * tpf;
+    const int y0 = (tl / tpx) * TH, x0 = (tl % tpx) * TW;
+
+    if (wave >= NW) {
+        // ================= loader wave =================
+        const int lw = wave - NW;
+        const int rsub = lane >> 3, cpos = lane & 7;
+        constexpr int MAXG = (NG + LW - 1) / LW;
+        const int np = (NG - lw + LW - 1) / LW;
+        const float* abase[MAXG];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) {
+            const int g = lw + LW * i;
+            const int hr = g * 8 + rsub;
+            const int hy = hr / HW2, hx = hr - hy * HW2;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NG && hr < HRT && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            abase[i] = ok ? p.t1 + (((long)b0 * p.H + y) * p.W + x) * C + (cpos ^ patch_key<TW>(hy, hx)) * CE : p.zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        const float *bsrc2[2], *bsrc3[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (lw * 2 + i) * 8 + rsub;
+            bsrc2[i] = p.w2 + (long)row * (9 * C) + (cpos ^ ((row >> 1) & 7)) * CE;
+            bsrc3[i] = p.w3 + (long)row * C + (cpos ^ ((row >> 1) & 7)) * CE;
+        }
+        auto issue_patch = [&](int c) {
+            unsigned char* pbuf = lds + P_OFF + (c & 1) * PB;
+#pragma unroll
+            for (int i = 0; i < MAXG; ++i) {
+                const int g = lw + LW * i;
+                if (g < NG) dma16(abase[i] + (((okmask >> i) & 1u) ? c * KE : 0), pbuf + g * 1024);
+            }
+        };
+        auto issue_w = [&](int j) {
+            unsigned char* sb = lds + (j % WR) * WSLOT;
+            if (j < NJ1) {
+                const int c = j / 9, t = j - c * 9;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dma16(bsrc2[i] + (long)t * C + c * KE, sb + (lw * 2 + i) * 1024);
+            } else {
+                const int q = j - NJ1, n = q >> 1, kt = q & 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dma16(bsrc3[i] + (long)n * 64 * C + kt * KE, sb + (lw * 2 + i) * 1024);
+            }
+        };
+        issue_patch(0);
+        issue_w(0);
+        issue_w(1);
+        for (int j = 0; j < NJ; ++j) {
+            const int c = j / 9, t = j - c * 9;
+            int younger = (j + 1 < NJ) ? 2 : 0;
+            if (j < NJ1 && (t == 4 || t == 5) && c == 0) younger += np;
+            wait_vmcnt_n(younger);
+            __builtin_amdgcn_s_barrier();
+            if (j + 2 < NJ) issue_w(j + 2);
+            if (j == 3) issue_patch(1);
+            if (j == NJ1 - 1) __builtin_amdgcn_s_barrier();          // the compute waves' "patches are dead" barrier
+        }
+        return;
+    }
+
+    // ================= compute wave: pixel tiles 2 wave, 2 wave + 1 (64 rows) through both phases =================
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int hb[TM], hy0[TM], hx0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wave * TM + i) * 32 + lrow;
+        const int y = m / TW, x = m - y * TW;
+        hb[i] = y * HW2 + x;
+        hy0[i] = y; hx0[i] = x;
+    }
+    auto mma3 = [&](const u32x4 (&ah)[TM], const u32x4 (&al)[TM], const u32x4 (&bh)[TN], const u32x4 (&bl)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                acc[i][jj] = mfma_bf16(ah[i], bh[jj], acc[i][jj]);
+                acc[i][jj] = mfma_bf16(ah[i], bl[jj], acc[i][jj]);
+                acc[i][jj] = mfma_bf16(al[i], bh[jj], acc[i][jj]);
+            }
+    };
+    // ---------------- phase 1: the 3x3 (conv3x3_patch_x3_kernel's loop)
+    {
+        int c = 0, t = 0;
+        for (int j = 0; j < NJ1; ++j) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned a_base = lds_base + P_OFF + (c & 1) * PB, b_base = lds_base + (j % WR) * WSLOT;
+            const int ky = t / 3, kx = t - ky * 3;
+            unsigned arow[TM], asw[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                arow[i] = a_base + (hb[i] + ky * HW2 + kx) * ROWB;
+                asw[i] = patch_key<TW>(hy0[i] + ky, hx0[i] + kx);
+            }
+            u32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            auto frag_read = [&](int s2, int buf) {
+                const int ch = 2 * s2 + lhalf;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[buf][i] = lds_read_b128(arow[i] + ((ch ^ asw[i]) << 4));
+                    al[buf][i] = lds_read_b128(arow[i] + (((4 + ch) ^ asw[i]) << 4));
+                }
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    bh[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, ch));
+                    bl[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, 4 + ch));
+                }
+            };
+            frag_read(0, 0);
+            lds_wait();
+            frag_read(1, 1);
+            mma3(ah[0], al[0], bh[0], bl[0]);
+            lds_wait();
+            mma3(ah[1], al[1], bh[1], bl[1]);
+            if (++t == 9) { t = 0; ++c; }
+        }
+    }
+    __builtin_amdgcn_s_barrier();                            // every wave is done with the patches: t2 and the y-chunk staging take their place
+    asm volatile("" ::: "memory");
+    // ---------------- t2 = relu(acc + b2) -> LDS (fp32, this wave's 64 rows), then split in place: row = 256 B = two [32 hi | 32 lo] groups,
+    // 16-byte slot (8 g + chunk) ^ (row & 15)
+    float* T2f = reinterpret_cast<float*>(lds + T2_OFF);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wave * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                T2f[row * 64 + j * 32 + lrow] = acc[i][j][r];
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const int cg = lane & 7;
+        const float4 bb0 = *reinterpret_cast<const float4*>(p.b2 + cg * 8), bb1 = *reinterpret_cast<const float4*>(p.b2 + cg * 8 + 4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = wave * 64 + it * 8 + (lane >> 3);
+            const float4 v0 = *reinterpret_cast<const float4*>(T2f + row * 64 + cg * 8), v1 = *reinterpret_cast<const float4*>(T2f + row * 64 + cg * 8 + 4);
+            float v[8] = {v0.x + bb0.x, v0.y + bb0.y, v0.z + bb0.z, v0.w + bb0.w, v1.x + bb1.x, v1.y + bb1.y, v1.z + bb1.z, v1.w + bb1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            uint32_t hi[4], lo[4];
+            split8_store_x3(v, hi, lo);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the row's eight lanes have their 32 bytes before any of them writes
+            const int g8 = (cg >> 2) * 8, cq = cg & 3, key = row & 15;
+            unsigned char* rb = lds + T2_OFF + row * 256;
+            *reinterpret_cast<uint4*>(rb + (((g8 + cq) ^ key) << 4)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(rb + (((g8 + 4 + cq) ^ key) << 4)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ---------------- phase 2: y chunk n = relu(W3[64 n .. 64 n + 63] t2 + b3 + x), K = 64 = two K-tiles
+    float* YCf = reinterpret_cast<float*>(lds + YC_OFF);
+    unsigned trow[TM], tkey[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wave * TM + i) * 32 + lrow;
+        trow[i] = lds_base + T2_OFF + row * 256;
+        tkey[i] = row & 15;
+    }
+    const int cg = lane & 7;
+    auto item_ofs = [&](int it, int nch) {                   // float offset of (this lane's row of item `it`, the 32-channel group of channel nch) in x / y
+        const int row = wave * 64 + it * 8 + (lane >> 3);
+        const int yy = row / TW, xx = row - yy * TW;
+        return ((((long)b0 * p.H + y0 + yy) * p.W + x0 + xx)) * C4 + (nch & ~31);
+    };
+    for (int n = 0; n < 4; ++n) {
+        // the chunk's residual: every item's (hi, lo) chunk pair is requested HERE, in front of the chunk's MFMAs - the store pass below is the only
+        // consumer, and with one compute wave per SIMD nothing else would hide the round trip
+        const int nch = n * 64 + cg * 8, cq = (nch & 31) >> 3;
+        u32x4 rh[8], rl[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const u32x4* xs = reinterpret_cast<const u32x4*>(p.x + item_ofs(it, nch));
+            rh[it] = xs[cq]; rl[it] = xs[4 + cq];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int j = NJ1 + 2 * n + kt;
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned b_base = lds_base + (j % WR) * WSLOT;
+            u32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            auto frag_read = [&](int s2, int buf) {
+                const int ch = 2 * s2 + lhalf;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + ch) ^ tkey[i]) << 4));
+                    al[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + 4 + ch) ^ tkey[i]) << 4));
+                }
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    bh[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, ch));
+                    bl[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, 4 + ch));
+                }
+            };
+            frag_read(0, 0);
+            lds_wait();
+            frag_read(1, 1);
+            mma3(ah[0], al[0], bh[0], bl[0]);
+            lds_wait();
+            mma3(ah[1], al[1], bh[1], bl[1]);
+        }
+        // the chunk's store pass, this wave's 64 rows: every item's residual chunks requested first
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wave * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    YCf[row * 64 + j * 32 + lrow] = acc[i][j][r];
+                }
+        const float4 bb0 = *reinterpret_cast<const float4*>(p.b3 + nch), bb1 = *reinterpret_cast<const float4*>(p.b3 + nch + 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = wave * 64 + it * 8 + (lane >> 3);
+            const float4 v0 = *reinterpret_cast<const float4*>(YCf + row * 64 + cg * 8), v1 = *reinterpret_cast<const float4*>(YCf + row * 64 + cg * 8 + 4);
+            float v[8] = {v0.x + bb0.x, v0.y + bb0.y, v0.z + bb0.z, v0.w + bb0.w, v1.x + bb1.x, v1.y + bb1.y, v1.z + bb1.z, v1.w + bb1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[2 * q] += __uint_as_float(rh[it][q] << 16) + __uint_as_float(rl[it][q] << 16);
+                v[2 * q + 1] += __uint_as_float(rh[it][q] & 0xffff0000u) + __uint_as_float(rl[it][q] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            uint32_t hi[4], lo[4];
+            split8_store_x3(v, hi, lo);
+            u32x4* ys = reinterpret_cast<u32x4*>(p.y + item_ofs(it, nch));
+            const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+            if (p.nt & 4) { __builtin_nontemporal_store(vh, ys + cq); __builtin_nontemporal_store(vl, ys + 4 + cq); }
+            else { ys[cq] = vh; ys[4 + cq] = vl; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the staging rows are free for the next chunk's accumulators)
+    }
+}
+
+void launch_res2_tail_x3(const void* t1, const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* zeros, void* y,
+                         int B, int H, int W, int rev, hipStream_t st) {
+    Res2TailX3Args a{};
+    a.t1 = static_cast<const float*>(t1); a.x = static_cast<const float*>(x); a.w2 = static_cast<const float*>(w2); a.b2 = b2;
+    a.w3 = static_cast<const float*>(w3); a.b3 = b3; a.zeros = static_cast<const float*>(zeros); a.y = static_cast<float*>(y);
+    a.B = B; a.H = H; a.W = W; a.rev = rev;
+    a.nt = tune_get("NT", 3) | (tune_get("NT_X3", 1) << 2);
+    ConvArgs d{};
+    d.B = B; d.H = H; d.W = W; d.Ho = H; d.Wo = W; d.Cin = 64; d.Cout = 256; d.KH = -4; d.KW = -4; d.stride = 1; d.res = x;     // KH = -4: "3x3 + expand" row of the layer report
+    void* tok = prof_begin(d, 4, st);
+    hipLaunchKernelGGL(res2_tail_x3_kernel, dim3(B * (H / 16) * (W / 16)), dim3(512), 0, st, a);
+    prof_end(tok, st);
+}
+
 static bool patch3x3_x3_ok(const ConvArgs& a) {              // res2's 3x3 in the split activation format; the shape only, never the batch
     return a.x3 == 2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.res && !a.x2 && a.Cin == 64 && a.Cout == 64 &&
            a.H == a.W && a.H % 16 == 0 && a.Ho == a.H && a.Wo == a.W && a.zeros;

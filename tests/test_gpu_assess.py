@@ -204,6 +204,30 @@ def test_bf16x3_patch_kernel_of_res2_3x3_against_the_per_tap_kernel(dev, gold):
         print(f"x3 patch 3x3, B={B}: res2 max abs diff {np.abs(a - b).max():.2e} of {scale:.2e}; scores max rel diff {np.abs(out[1][1] / out[0][1] - 1).max():.2e}")
 
 
+def test_bf16x3_fused_3x3_and_expand_of_res2_equals_the_two_launches(dev):
+    """res2_tail_x3_kernel (conv.hip, round 6: the identity blocks of res2 in the three-pass mode behind their conv1 - 3x3 on the LDS-resident halo
+    patch, t2 split in place in LDS, four 64-channel chunks of conv3 + bias + residual, split stores) against the two launches it replaces
+    (conv3x3_patch_x3_kernel, then the 128 x 128-tile expand layer; tunable FUSE_TAIL_X3 = 0): the same products in the same order per output
+    element - res2's output and the scores are bit-identical, on edge masks, a single frame and a ragged batch."""
+    from ivos_w_amd import _lib as L
+    nx = make_net(dev, "bf16x3")
+    for B, edge in ((8, True), (1, False), (5, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        out = {}
+        for mode in (1, 0):
+            L.tune_set(b"FUSE_TAIL_X3", mode)
+            try:
+                _, r2 = nx.forward_tap(ttf, ttp, "res2")
+                out[mode] = (r2.cpu().numpy(), nx(ttf, ttp).cpu().numpy())
+            finally:
+                L.tune_set(b"FUSE_TAIL_X3", 1)
+        a, b = out[1][0], out[0][0]
+        assert a.shape == b.shape == (B, 64, 64, 256) and np.isfinite(a).all() and (a > 0).mean() > 0.1
+        print(f"x3 fused tail, B={B}: res2 max abs diff {np.abs(a - b).max():.2e}, bit-identical {bool(np.array_equal(a, b))}")
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(out[1][1], out[0][1])
+
+
 def test_fp32_b3_and_chunking(dev, gold):
     _, _, ttf, ttp = inputs(dev, 3, False)
     net = make_net(dev, "fp32", chunk=2)                  # ragged last chunk
