@@ -35,6 +35,10 @@ of the chip (the guide reports 1.75 - 1.9 PFLOP/s with inline asm) - and the ach
 the 2.5 PFLOP/s peak.
 `dqn.dp_critical_path` (round 5, N = 1): the DQN step re-run in a child through the N > 1 branch on nccl with ONE rank (`--gpus 1 --force-dist`:
 process group, all-reduce of the gradient arena in every step, clamp + Adam with 1/world) against the fused single-GPU step.
+`dqn.collectives` (N > 1): `backend` = the step timed through torch.distributed's all-reduce (= `dqn.value`: the product default), with the process
+group's own world size and backend string; `p2p` = the one-shot xGMI peer-to-peer all-reduce fused with clamp + Adam (opt-in in the product), attempted by
+default as the LAST act of the run - after every other number of the line exists - under LineGuard: a watchdog child holds the finished line and prints it
+if the process dies inside that leg; `dqn.scaling_vs_1gpu` = whole-job steps/s over the committed single-GPU rate.  IVOSW_BENCH_P2P=0 skips the leg.
 `checked`: after the timed region a sample of the B=256 scores is compared with the oracle on the CPU (and the fp32 parity
 mode, which is also timed: `fp32`); the line is not printed if they disagree.  cpu_baseline: torch-CPU restatements of the
 reference path (kind "port") on bounded samples, rank 0, N=1 only.
