@@ -637,6 +637,13 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 x = y;
                 continue;
             }
+            if (dtype == IVOSW_F32X3 && s == 1 && bp.ds < 0 && hw == 32 && c2.K == 3 && c2.stride == 1 && c2.Cin == 128 && c2.Cout == 128 && c3.Cin == 128 &&
+                c3.Cout == 512 && tune_get("FUSE_TAIL3_X3", 1)) {
+                launch_res3_tail_x3(bf.m1, x, base + c2.w_off, reinterpret_cast<const float*>(base + c2.b_off), base + c3.w_off,
+                                    reinterpret_cast<const float*>(base + c3.b_off), base + P.zero_off, y, nb, hw, hw, next_dir(), st);
+                x = y;
+                continue;
+            }
             mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
             const void* idt = x;
             if (bp.ds >= 0 && tune_get("FUSE_DS", 1)) {

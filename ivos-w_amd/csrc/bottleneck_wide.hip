@@ -224,6 +224,16 @@ __device__ __forceinline__ void bneck_wide_body(const BneckWideArgs& p, unsigned
             // 128-B row of zeros parked in the (still unused) store-staging area instead of being masked afterwards
             unsigned roff[NPT];                      // byte offset of the row; its swizzle key is (row >> 1) & 7 = (roff >> 8) & 7
             unsigned vmask = 0;
+            // the lane's pixel coordinates are rebuilt from the lane id HERE, once per tap (two v_mbcnt + a few ALU ops): kept across the phase they
+            // were spilled at 256 registers, and their reload - a scratch load followed by vmcnt(0) - opened every tap (round 6, late)
+            unsigned lid;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+            const int lr_ = (int)(lid & 31);
+#pragma unroll
+            for (int i = 0; i < NPT; ++i) {
+                const int q_ = i * 32 + lr_;
+                pfr[i] = q_ / (HW * HW); pyy[i] = (q_ / HW) % HW; pxx[i] = q_ % HW;
+            }
 #pragma unroll
             for (int i = 0; i < NPT; ++i) {
                 const int y = pyy[i] + ky, x = pxx[i] + kx;

@@ -1475,6 +1475,311 @@ void launch_res2_tail_x3(const void* t1, const void* x, const void* w2, const fl
     prof_end(tok, st);
 }
 
+// ---------------------------------------------------------------- the same for res3's identity blocks (128 -> 128 3x3 on 32 x 32 frames, 128 -> 512 expand + residual)
+// Tile = 8 x 16 pixels (t2 of a 256-pixel tile would be 128 KB): 10 x 18 halo patch per 32-channel slice (four slices, two buffers), 16-KB weight
+// tiles (128 output channels x one K-tile) through a 3-slot ring - 36 (slice, tap) tiles of the 3x3, then 16 (128-channel double chunk, K-tile) tiles
+// of conv3.  Compute wave (wm, wn) owns pixel tiles 2 wm, 2 wm + 1 x channel tiles 2 wn, 2 wn + 1 of whatever 128 channels are being produced, so a
+// row of t2 is written by two waves: one more barrier between the in-place split and phase 2.  The store pass stages a wave's 64 rows x 32 channels at
+// a time in a private 8-KB tile.  3x3 in slice-major K order (the per-tap kernel it replaces runs tap-major): equal to it up to fp32 summation noise
+// and single flips of the split format's last bit, like conv3x3_patch_x3_kernel.  LDS (144 KB): ring [0, 48 K) | patches -> t2 [48 K, 112 K) | staging.
+__global__ __launch_bounds__(512) void res3_tail_x3_kernel(Res2TailX3Args p) {
+    constexpr int TH = 8, TW = 16, HW2 = TW + 2, HRT = (TH + 2) * HW2, NG = (HRT + 7) / 8, PB = NG * 1024;     // 180 halo rows, 23 groups
+    constexpr int NW = 4, LW = 4, TM = 2, TN = 2, KE = 32, CE = 4, C = 128, C4 = 512, NC = C / KE;
+    constexpr int WSLOT = 128 * ROWB, WR = 3, P_OFF = WR * WSLOT, T2_OFF = P_OFF, T2_ROW = C * 4, YC_OFF = T2_OFF + 128 * T2_ROW;
+    constexpr int LDS_BYTES = YC_OFF + NW * 8192;
+    constexpr int NJ1 = NC * 9, NJ = NJ1 + 4 * NC;
+    static_assert(P_OFF + 2 * PB <= YC_OFF && LDS_BYTES <= 163840, "LDS map");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = p.rev ? (int)gridDim.x - 1 - L : L;
+    const int tpx = p.W / TW, tpf = (p.H / TH) * tpx;
+    const int b0 = tile_m / tpf, tl = tile_m - b0 * tpf;
+    const int y0 = (tl / tpx) * TH, x0 = (tl % tpx) * TW;
+
+    if (wave >= NW) {
+        // ================= loader wave =================
+        const int lw = wave - NW;
+        const int rsub = lane >> 3, cpos = lane & 7;
+        constexpr int MAXG = (NG + LW - 1) / LW;             // 6
+        const int np = (NG - lw + LW - 1) / LW;
+        const float* abase[MAXG];
+        unsigned okmask = 0;
+#pragma unroll
+        for (int i = 0; i < MAXG; ++i) {
+            const int g = lw + LW * i;
+            const int hr = g * 8 + rsub;
+            const int hy = hr / HW2, hx = hr - hy * HW2;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = g < NG && hr < HRT && y >= 0 && y < p.H && x >= 0 && x < p.W;
+            abase[i] = ok ? p.t1 + (((long)b0 * p.H + y) * p.W + x) * C + (cpos ^ patch_key<TW>(hy, hx)) * CE : p.zeros;
+            okmask |= ok ? (1u << i) : 0u;
+        }
+        const float *bsrc2[4], *bsrc3[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (lw * 4 + i) * 8 + rsub;         // 0 .. 127
+            bsrc2[i] = p.w2 + (long)row * (9 * C) + (cpos ^ ((row >> 1) & 7)) * CE;
+            bsrc3[i] = p.w3 + (long)row * C + (cpos ^ ((row >> 1) & 7)) * CE;
+        }
+        auto issue_patch = [&](int c) {
+            unsigned char* pbuf = lds + P_OFF + (c & 1) * PB;
+#pragma unroll
+            for (int i = 0; i < MAXG; ++i) {
+                const int g = lw + LW * i;
+                if (g < NG) dma16(abase[i] + (((okmask >> i) & 1u) ? c * KE : 0), pbuf + g * 1024);
+            }
+        };
+        auto issue_w = [&](int j) {
+            unsigned char* sb = lds + (j % WR) * WSLOT;
+            if (j < NJ1) {
+                const int c = j / 9, t = j - c * 9;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dma16(bsrc2[i] + (long)t * C + c * KE, sb + (lw * 4 + i) * 1024);
+            } else {
+                const int q = j - NJ1, n2 = q >> 2, kt = q & 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dma16(bsrc3[i] + (long)n2 * 128 * C + kt * KE, sb + (lw * 4 + i) * 1024);
+            }
+        };
+        issue_patch(0);
+        issue_w(0);
+        issue_w(1);
+        for (int j = 0; j < NJ; ++j) {
+            const int c = j / 9, t = j - c * 9;
+            int younger = (j + 1 < NJ) ? 4 : 0;
+            if (j < NJ1 && (t == 4 || t == 5) && c + 1 < NC) younger += np;
+            wait_vmcnt_n(younger);
+            __builtin_amdgcn_s_barrier();
+            if (j + 2 < NJ) issue_w(j + 2);
+            if (j < NJ1 && t == 3 && c + 1 < NC) issue_patch(c + 1);
+            if (j == NJ1 - 1) {                              // the compute waves' "patches are dead" and "t2 is complete" barriers
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        return;
+    }
+
+    // ================= compute wave (wm, wn): pixel tiles 2 wm, 2 wm + 1 x channel tiles 2 wn, 2 wn + 1 =================
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    int hb[TM], hy0[TM], hx0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 32 + lrow;
+        const int y = m / TW, x = m - y * TW;
+        hb[i] = y * HW2 + x;
+        hy0[i] = y; hx0[i] = x;
+    }
+    auto mma3 = [&](const u32x4 (&ah)[TM], const u32x4 (&al)[TM], const u32x4 (&bh)[TN], const u32x4 (&bl)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                acc[i][jj] = mfma_bf16(ah[i], bh[jj], acc[i][jj]);
+                acc[i][jj] = mfma_bf16(ah[i], bl[jj], acc[i][jj]);
+                acc[i][jj] = mfma_bf16(al[i], bh[jj], acc[i][jj]);
+            }
+    };
+    {
+        int c = 0, t = 0;
+        for (int j = 0; j < NJ1; ++j) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned a_base = lds_base + P_OFF + (c & 1) * PB, b_base = lds_base + (j % WR) * WSLOT;
+            const int ky = t / 3, kx = t - ky * 3;
+            unsigned arow[TM], asw[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                arow[i] = a_base + (hb[i] + ky * HW2 + kx) * ROWB;
+                asw[i] = patch_key<TW>(hy0[i] + ky, hx0[i] + kx);
+            }
+            u32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            auto frag_read = [&](int s2, int buf) {
+                const int ch = 2 * s2 + lhalf;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[buf][i] = lds_read_b128(arow[i] + ((ch ^ asw[i]) << 4));
+                    al[buf][i] = lds_read_b128(arow[i] + (((4 + ch) ^ asw[i]) << 4));
+                }
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    bh[buf][jj] = lds_read_b128(b_base + swz((wn * TN + jj) * 32 + lrow, ch));
+                    bl[buf][jj] = lds_read_b128(b_base + swz((wn * TN + jj) * 32 + lrow, 4 + ch));
+                }
+            };
+            frag_read(0, 0);
+            lds_wait();
+            frag_read(1, 1);
+            mma3(ah[0], al[0], bh[0], bl[0]);
+            lds_wait();
+            mma3(ah[1], al[1], bh[1], bl[1]);
+            if (++t == 9) { t = 0; ++c; }
+        }
+    }
+    __builtin_amdgcn_s_barrier();                            // every wave is done with the patches
+    asm volatile("" ::: "memory");
+    // t2 = relu(acc + b2): this wave's 64 rows x 64 channels as fp32, then split in place; row = 512 B = four [32 hi | 32 lo] groups, slot (8 g + chunk) ^ (row & 15)
+    float* T2f = reinterpret_cast<float*>(lds + T2_OFF);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                T2f[row * C + wn * 64 + j * 32 + lrow] = acc[i][j][r];
+            }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        const int cg = lane & 7;
+        const float4 bb0 = *reinterpret_cast<const float4*>(p.b2 + wn * 64 + cg * 8), bb1 = *reinterpret_cast<const float4*>(p.b2 + wn * 64 + cg * 8 + 4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = wm * 64 + it * 8 + (lane >> 3);
+            const float4 v0 = *reinterpret_cast<const float4*>(T2f + row * C + wn * 64 + cg * 8), v1 = *reinterpret_cast<const float4*>(T2f + row * C + wn * 64 + cg * 8 + 4);
+            float v[8] = {v0.x + bb0.x, v0.y + bb0.y, v0.z + bb0.z, v0.w + bb0.w, v1.x + bb1.x, v1.y + bb1.y, v1.z + bb1.z, v1.w + bb1.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+            uint32_t hi[4], lo[4];
+            split8_store_x3(v, hi, lo);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the eight lanes of a (row, 64-channel half) have their 32 bytes before any of them writes
+            const int g8 = (wn * 2 + (cg >> 2)) * 8, cq = cg & 3, key = row & 15;
+            unsigned char* rb = lds + T2_OFF + row * T2_ROW;
+            *reinterpret_cast<uint4*>(rb + (((g8 + cq) ^ key) << 4)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(rb + (((g8 + 4 + cq) ^ key) << 4)) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // t2 complete: a row's two 64-channel halves come from two waves
+    asm volatile("" ::: "memory");
+    // ---------------- phase 2: y[128 n2 + 64 wn .. + 63] = relu(W3 t2 + b3 + x), K = 128 = four K-tiles per 128-channel double chunk
+    float* YCf = reinterpret_cast<float*>(lds + YC_OFF + wave * 8192);       // private staging: 64 rows x 32 channels
+    unsigned trow[TM], tkey[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + lrow;
+        trow[i] = lds_base + T2_OFF + row * T2_ROW;
+        tkey[i] = row & 15;
+    }
+    const int cgl = lane & 3;
+    auto item_ofs = [&](int it, int nch) {
+        const int row = wm * 64 + it * 16 + (lane >> 2);
+        const int yy = row / TW, xx = row - yy * TW;
+        return ((((long)b0 * p.H + y0 + yy) * p.W + x0 + xx)) * C4 + (nch & ~31);
+    };
+    for (int n2 = 0; n2 < 4; ++n2) {
+        u32x4 rh[1][4], rl[1][4];                            // the first 32-channel half's residual, requested in front of the double chunk's MFMAs (the second
+        {                                                    // half's goes out under the first half's store pass: both halves up front spilled 24 registers)
+            const int nch = n2 * 128 + wn * 64 + cgl * 8;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const u32x4* xs = reinterpret_cast<const u32x4*>(p.x + item_ofs(it, nch));
+                rh[0][it] = xs[cgl]; rl[0][it] = xs[4 + cgl];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NC; ++kt) {
+            const int j = NJ1 + NC * n2 + kt;
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned b_base = lds_base + (j % WR) * WSLOT;
+            u32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            auto frag_read = [&](int s2, int buf) {
+                const int ch = 2 * s2 + lhalf;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + ch) ^ tkey[i]) << 4));
+                    al[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + 4 + ch) ^ tkey[i]) << 4));
+                }
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    bh[buf][jj] = lds_read_b128(b_base + swz((wn * TN + jj) * 32 + lrow, ch));
+                    bl[buf][jj] = lds_read_b128(b_base + swz((wn * TN + jj) * 32 + lrow, 4 + ch));
+                }
+            };
+            frag_read(0, 0);
+            lds_wait();
+            frag_read(1, 1);
+            mma3(ah[0], al[0], bh[0], bl[0]);
+            lds_wait();
+            mma3(ah[1], al[1], bh[1], bl[1]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj) {                    // store pass, 32 channels at a time through the private staging tile
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) YCf[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * 32 + lrow] = acc[i][jj][r];
+            const int nch = n2 * 128 + wn * 64 + jj * 32 + cgl * 8;
+            u32x4 qh[4], ql[4];                              // this half's residual; the next half's is requested before this half is processed
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { qh[it] = rh[0][it]; ql[it] = rl[0][it]; }
+            if (jj + 1 < TN) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const u32x4* xs = reinterpret_cast<const u32x4*>(p.x + item_ofs(it, nch + 32));
+                    rh[0][it] = xs[cgl]; rl[0][it] = xs[4 + cgl];
+                }
+            }
+            const float4 bb0 = *reinterpret_cast<const float4*>(p.b3 + nch), bb1 = *reinterpret_cast<const float4*>(p.b3 + nch + 4);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rl_ = it * 16 + (lane >> 2);
+                const float4 v0 = *reinterpret_cast<const float4*>(YCf + rl_ * 32 + cgl * 8), v1 = *reinterpret_cast<const float4*>(YCf + rl_ * 32 + cgl * 8 + 4);
+                float v[8] = {v0.x + bb0.x, v0.y + bb0.y, v0.z + bb0.z, v0.w + bb0.w, v1.x + bb1.x, v1.y + bb1.y, v1.z + bb1.z, v1.w + bb1.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += __uint_as_float(qh[it][q] << 16) + __uint_as_float(ql[it][q] << 16);
+                    v[2 * q + 1] += __uint_as_float(qh[it][q] & 0xffff0000u) + __uint_as_float(ql[it][q] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                uint32_t hi[4], lo[4];
+                split8_store_x3(v, hi, lo);
+                u32x4* ys = reinterpret_cast<u32x4*>(p.y + item_ofs(it, nch));
+                const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
+                if (p.nt & 4) { __builtin_nontemporal_store(vh, ys + cgl); __builtin_nontemporal_store(vl, ys + 4 + cgl); }
+                else { ys[cgl] = vh; ys[4 + cgl] = vl; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+void launch_res3_tail_x3(const void* t1, const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* zeros, void* y,
+                         int B, int H, int W, int rev, hipStream_t st) {
+    Res2TailX3Args a{};
+    a.t1 = static_cast<const float*>(t1); a.x = static_cast<const float*>(x); a.w2 = static_cast<const float*>(w2); a.b2 = b2;
+    a.w3 = static_cast<const float*>(w3); a.b3 = b3; a.zeros = static_cast<const float*>(zeros); a.y = static_cast<float*>(y);
+    a.B = B; a.H = H; a.W = W; a.rev = rev;
+    a.nt = tune_get("NT", 3) | (tune_get("NT_X3", 1) << 2);
+    ConvArgs d{};
+    d.B = B; d.H = H; d.W = W; d.Ho = H; d.Wo = W; d.Cin = 128; d.Cout = 512; d.KH = -4; d.KW = -4; d.stride = 1; d.res = x;
+    void* tok = prof_begin(d, 4, st);
+    hipLaunchKernelGGL(res3_tail_x3_kernel, dim3(B * (H / 8) * (W / 16)), dim3(512), 0, st, a);
+    prof_end(tok, st);
+}
+
 static bool patch3x3_x3_ok(const ConvArgs& a) {              // res2's 3x3 in the split activation format; the shape only, never the batch
     return a.x3 == 2 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.res && !a.x2 && a.Cin == 64 && a.Cout == 64 &&
            a.H == a.W && a.H % 16 == 0 && a.Ho == a.H && a.Wo == a.W && a.zeros;

@@ -46,6 +46,26 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
         case 18: wait_vmcnt<18>(); break;
         case 19: wait_vmcnt<19>(); break;
         case 20: wait_vmcnt<20>(); break;
+        case 21: wait_vmcnt<21>(); break;
+        case 22: wait_vmcnt<22>(); break;
+        case 23: wait_vmcnt<23>(); break;
+        case 24: wait_vmcnt<24>(); break;
+        case 25: wait_vmcnt<25>(); break;
+        case 26: wait_vmcnt<26>(); break;
+        case 27: wait_vmcnt<27>(); break;
+        case 28: wait_vmcnt<28>(); break;
+        case 29: wait_vmcnt<29>(); break;
+        case 30: wait_vmcnt<30>(); break;
+        case 31: wait_vmcnt<31>(); break;
+        case 32: wait_vmcnt<32>(); break;
+        case 33: wait_vmcnt<33>(); break;
+        case 34: wait_vmcnt<34>(); break;
+        case 35: wait_vmcnt<35>(); break;
+        case 36: wait_vmcnt<36>(); break;
+        case 37: wait_vmcnt<37>(); break;
+        case 38: wait_vmcnt<38>(); break;
+        case 39: wait_vmcnt<39>(); break;
+        case 40: wait_vmcnt<40>(); break;
         default: wait_vmcnt<0>(); break;
     }
 }

@@ -228,6 +228,33 @@ def test_bf16x3_fused_3x3_and_expand_of_res2_equals_the_two_launches(dev):
         np.testing.assert_array_equal(out[1][1], out[0][1])
 
 
+def test_bf16x3_fused_3x3_and_expand_of_res3_against_the_two_launches(dev, gold):
+    """res3_tail_x3_kernel (conv.hip, round 6: res3's identity blocks of the three-pass mode behind their conv1 on 8 x 16-pixel tiles - 3x3 on the
+    LDS-resident halo patch, t2 split in place, 128-channel double chunks of conv3 + bias + residual) against the per-tap 3x3 kernel + the expand
+    layer it replaces (tunable FUSE_TAIL3_X3 = 0).  The 3x3 sums in slice-major instead of tap-major order: res3's output agrees to fp32 summation
+    noise plus single flips of the split format's last bit, the scores to 5e-6, the reference goldens hold at the fp32 bars."""
+    from ivos_w_amd import _lib as L
+    nx = make_net(dev, "bf16x3")
+    for tag, B, edge in (("B8", 8, True), ("B1", 1, False), ("B5", 5, False)):
+        _, _, ttf, ttp = inputs(dev, B, edge)
+        out = {}
+        for mode in (1, 0):
+            L.tune_set(b"FUSE_TAIL3_X3", mode)
+            try:
+                _, r3 = nx.forward_tap(ttf, ttp, "res3")
+                out[mode] = (r3.cpu().numpy(), nx(ttf, ttp).cpu().numpy())
+            finally:
+                L.tune_set(b"FUSE_TAIL3_X3", 1)
+        a, b = out[1][0], out[0][0]
+        assert a.shape == b.shape == (B, 32, 32, 512) and np.isfinite(a).all() and (a > 0).mean() > 0.1
+        scale = np.abs(b).max()
+        print(f"x3 res3 tail, B={B}: res3 max abs diff {np.abs(a - b).max():.2e} mean {np.abs(a - b).mean():.2e} of {scale:.2e}; scores max rel diff {np.abs(out[1][1] / out[0][1] - 1).max():.2e}")
+        assert np.abs(a - b).max() <= 4 * 2.0 ** -16 * scale and np.abs(a - b).mean() <= 2e-6 * scale, (np.abs(a - b).max(), np.abs(a - b).mean(), scale)
+        np.testing.assert_allclose(out[1][1], out[0][1], rtol=5e-6)
+        if tag in ("B8", "B1"):
+            np.testing.assert_allclose(out[1][1], gold[f"{tag}_score"], rtol=1e-4)
+
+
 def test_fp32_b3_and_chunking(dev, gold):
     _, _, ttf, ttp = inputs(dev, 3, False)
     net = make_net(dev, "fp32", chunk=2)                  # ragged last chunk
