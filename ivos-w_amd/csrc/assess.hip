@@ -644,6 +644,14 @@ static void assess_forward_range(const void* packed, int dtype, const float* tf,
                 x = y;
                 continue;
             }
+            if (dtype == IVOSW_F32X3 && s == 0 && bp.ds >= 0 && hw == 64 && c2.K == 3 && c2.stride == 1 && c2.Cin == 64 && c2.Cout == 64 && c3.Cin == 64 &&
+                c3.Cout == 256 && P.convs[bp.ds].Cin == 64 && P.convs[bp.ds].stride == 1 && tune_get("FUSE_DS", 1) && tune_get("FUSE_TAIL_X3", 1)) {
+                // res2's first block: 3x3 -> [conv3 | downsample] (K = 64 + 64, the block input as the second half) as one launch
+                launch_res2_tail_x3(bf.m1, nullptr, base + c2.w_off, reinterpret_cast<const float*>(base + c2.b_off), base + bp.cat_w_off,
+                                    reinterpret_cast<const float*>(base + bp.cat_b_off), base + P.zero_off, y, nb, hw, hw, next_dir(), st, x);
+                x = y;
+                continue;
+            }
             mk(c2, bf.m1, hw, ho, nullptr, bf.m2, 1);
             const void* idt = x;
             if (bp.ds >= 0 && tune_get("FUSE_DS", 1)) {

@@ -163,7 +163,7 @@ void launch_pack_stem(const float* w3, const float* w1, const float* g, const fl
 void launch_stem_pool(const void* roi, const void* w, const float* bias, int B, void* out, hipStream_t st, int rev = 0);
 // IVOSW_F32X3, res2's identity blocks behind their conv1: 3x3 (64 -> 64) -> conv3 (64 -> 256) + residual x, split layout throughout (conv.hip)
 void launch_res2_tail_x3(const void* t1, const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* zeros, void* y,
-                         int B, int H, int W, int rev, hipStream_t st);
+                         int B, int H, int W, int rev, hipStream_t st, const void* p2 = nullptr);   // p2: res2's first block ([conv3 | downsample], no residual)
 void launch_res3_tail_x3(const void* t1, const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* zeros, void* y,
                          int B, int H, int W, int rev, hipStream_t st);   // the same for res3's identity blocks (128 -> 128 3x3, 128 -> 512 expand)
 void launch_stem_pool_x3(const void* roi, const void* wsplit, const float* bias, int B, void* out, hipStream_t st, int rev = 0);   // IVOSW_F32X3: fp32 ROI in, split pooled map out

@@ -1186,15 +1186,20 @@ __global__ __launch_bounds__(512) void conv3x3_patch_x3_kernel(ConvArgs p) {
 // LDS (152 KB): ring [0, 24 K) | patch buffers [24 K, 106 K) -> t2 [24 K, 88 K) | y-chunk staging [88 K, 152 K).
 struct Res2TailX3Args {
     const float *t1, *x, *w2, *b2, *w3, *b3, *zeros;
+    const float* p2;             // DS (res2's first block): the block input, second K half of [conv3 | downsample]; x (the residual) is unused there
     float* y;
     int B, H, W, nt, rev;
 };
+// DS: res2's FIRST block - no residual; conv3 is [conv3 | downsample] along K (K = 128: t2, then the block input p2 at the tile's pixels, whose
+// fragments every compute wave takes straight from global memory into 64 registers once - the residual's registers are free there).
+template <bool DS>
 __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
     constexpr int TH = 16, TW = 16, HW2 = TW + 2, HRT = (TH + 2) * HW2, NG = (HRT + 7) / 8, PB = NG * 1024;
     constexpr int NW = 4, LW = 4, TM = 2, TN = 2, KE = 32, CE = 4, C = 64, C4 = 256;
     constexpr int WSLOT = 64 * ROWB, WR = 3, P_OFF = WR * WSLOT, T2_OFF = P_OFF, YC_OFF = T2_OFF + 256 * 256;
     constexpr int LDS_BYTES = YC_OFF + 256 * 256;
-    constexpr int NJ1 = 18, NJ = NJ1 + 8;                    // ring tiles: (slice, tap) of the 3x3, then (chunk, K-tile) of the expand layer
+    constexpr int NK2 = DS ? 4 : 2, K3 = NK2 * KE;           // K-tiles / K of the expand layer
+    constexpr int NJ1 = 18, NJ = NJ1 + 4 * NK2;              // ring tiles: (slice, tap) of the 3x3, then (chunk, K-tile) of the expand layer
     static_assert(P_OFF + 2 * PB <= LDS_BYTES && LDS_BYTES <= 163840, "LDS map");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1228,7 +1233,7 @@ __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
         for (int i = 0; i < 2; ++i) {
             const int row = (lw * 2 + i) * 8 + rsub;
             bsrc2[i] = p.w2 + (long)row * (9 * C) + (cpos ^ ((row >> 1) & 7)) * CE;
-            bsrc3[i] = p.w3 + (long)row * C + (cpos ^ ((row >> 1) & 7)) * CE;
+            bsrc3[i] = p.w3 + (long)row * K3 + (cpos ^ ((row >> 1) & 7)) * CE;
         }
         auto issue_patch = [&](int c) {
             unsigned char* pbuf = lds + P_OFF + (c & 1) * PB;
@@ -1245,9 +1250,9 @@ __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) dma16(bsrc2[i] + (long)t * C + c * KE, sb + (lw * 2 + i) * 1024);
             } else {
-                const int q = j - NJ1, n = q >> 1, kt = q & 1;
+                const int q = j - NJ1, n = q / NK2, kt = q - n * NK2;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) dma16(bsrc3[i] + (long)n * 64 * C + kt * KE, sb + (lw * 2 + i) * 1024);
+                for (int i = 0; i < 2; ++i) dma16(bsrc3[i] + (long)n * 64 * K3 + kt * KE, sb + (lw * 2 + i) * 1024);
             }
         };
         issue_patch(0);
@@ -1333,6 +1338,22 @@ __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
     }
     __builtin_amdgcn_s_barrier();                            // every wave is done with the patches: t2 and the y-chunk staging take their place
     asm volatile("" ::: "memory");
+    u32x4 pfh[DS ? TM : 1][2][2], pfl[DS ? TM : 1][2][2];    // DS: the block input's fragments [pixel tile][K-tile][step], requested under the t2 epilogue
+    if constexpr (DS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wave * TM + i) * 32 + lrow;
+            const int yy = row / TW, xx = row - yy * TW;
+            const u32x4* ps = reinterpret_cast<const u32x4*>(p.p2 + ((((long)b0 * p.H + y0 + yy) * p.W + x0 + xx)) * C);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    pfh[i][k2][s2] = ps[k2 * 8 + 2 * s2 + lhalf];
+                    pfl[i][k2][s2] = ps[k2 * 8 + 4 + 2 * s2 + lhalf];
+                }
+        }
+    }
     // ---------------- t2 = relu(acc + b2) -> LDS (fp32, this wave's 64 rows), then split in place: row = 256 B = two [32 hi | 32 lo] groups,
     // 16-byte slot (8 g + chunk) ^ (row & 15)
     float* T2f = reinterpret_cast<float*>(lds + T2_OFF);
@@ -1377,20 +1398,25 @@ __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
         tkey[i] = row & 15;
     }
     const int cg = lane & 7;
-    auto item_ofs = [&](int it, int nch) {                   // float offset of (this lane's row of item `it`, the 32-channel group of channel nch) in x / y
-        const int row = wave * 64 + it * 8 + (lane >> 3);
+    auto item_ofs = [&](int it, int nch, int ln = -1) {      // float offset of (this lane's row of item `it`, the 32-channel group of channel nch) in x / y
+        const int row = wave * 64 + it * 8 + ((ln < 0 ? lane : ln) >> 3);
         const int yy = row / TW, xx = row - yy * TW;
         return ((((long)b0 * p.H + y0 + yy) * p.W + x0 + xx)) * C4 + (nch & ~31);
     };
+#pragma unroll 1
     for (int n = 0; n < 4; ++n) {
+        int lr2 = lrow, ln2 = lane;                         // opaque per chunk: keeps the chunk loop's addresses from being precomputed (and spilled) outside it
+        asm volatile("" : "+v"(lr2), "+v"(ln2));
         // the chunk's residual: every item's (hi, lo) chunk pair is requested HERE, in front of the chunk's MFMAs - the store pass below is the only
         // consumer, and with one compute wave per SIMD nothing else would hide the round trip
         const int nch = n * 64 + cg * 8, cq = (nch & 31) >> 3;
-        u32x4 rh[8], rl[8];
+        u32x4 rh[DS ? 1 : 8], rl[DS ? 1 : 8];
+        if constexpr (!DS) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const u32x4* xs = reinterpret_cast<const u32x4*>(p.x + item_ofs(it, nch));
-            rh[it] = xs[cq]; rl[it] = xs[4 + cq];
+            for (int it = 0; it < 8; ++it) {
+                const u32x4* xs = reinterpret_cast<const u32x4*>(p.x + item_ofs(it, nch, ln2));
+                rh[it] = xs[cq]; rl[it] = xs[4 + cq];
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1399,23 +1425,50 @@ __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int j = NJ1 + 2 * n + kt;
+        for (int kt = 0; kt < NK2; ++kt) {
+            const int j = NJ1 + NK2 * n + kt;
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const unsigned b_base = lds_base + (j % WR) * WSLOT;
+            if (DS && kt >= 2) {
+                // the block input's K-tiles: the pixel fragments are in registers, only the weight fragments come from the ring
+                u32x4 bh[2][TN], bl[2][TN];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj) {
+                        bh[s2][jj] = lds_read_b128(b_base + swz(jj * 32 + lr2, 2 * s2 + lhalf));
+                        bl[s2][jj] = lds_read_b128(b_base + swz(jj * 32 + lr2, 4 + 2 * s2 + lhalf));
+                    }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (s2 == 0) { asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } else lds_wait();
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj) {
+                            acc[i][jj] = mfma_bf16(pfh[DS ? i : 0][kt & 1][s2], bh[s2][jj], acc[i][jj]);
+                            acc[i][jj] = mfma_bf16(pfh[DS ? i : 0][kt & 1][s2], bl[s2][jj], acc[i][jj]);
+                            acc[i][jj] = mfma_bf16(pfl[DS ? i : 0][kt & 1][s2], bh[s2][jj], acc[i][jj]);
+                        }
+                }
+                continue;
+            }
             u32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+            unsigned tk[TM];                             // (opaque per K-tile: sixteen precomputed fragment addresses per wave, hoisted out of the chunk loop, were
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { tk[i] = tkey[i]; asm volatile("" : "+v"(tk[i])); }     //  what the DS form spilled - and reloaded in every chunk)
             auto frag_read = [&](int s2, int buf) {
                 const int ch = 2 * s2 + lhalf;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    ah[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + ch) ^ tkey[i]) << 4));
-                    al[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + 4 + ch) ^ tkey[i]) << 4));
+                    ah[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + ch) ^ tk[i]) << 4));
+                    al[buf][i] = lds_read_b128(trow[i] + (((kt * 8 + 4 + ch) ^ tk[i]) << 4));
                 }
 #pragma unroll
                 for (int jj = 0; jj < TN; ++jj) {
-                    bh[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, ch));
-                    bl[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lrow, 4 + ch));
+                    bh[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lr2, ch));
+                    bl[buf][jj] = lds_read_b128(b_base + swz(jj * 32 + lr2, 4 + ch));
                 }
             };
             frag_read(0, 0);
@@ -1443,16 +1496,18 @@ __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
             const int row = wave * 64 + it * 8 + (lane >> 3);
             const float4 v0 = *reinterpret_cast<const float4*>(YCf + row * 64 + cg * 8), v1 = *reinterpret_cast<const float4*>(YCf + row * 64 + cg * 8 + 4);
             float v[8] = {v0.x + bb0.x, v0.y + bb0.y, v0.z + bb0.z, v0.w + bb0.w, v1.x + bb1.x, v1.y + bb1.y, v1.z + bb1.z, v1.w + bb1.w};
+            if constexpr (!DS) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[2 * q] += __uint_as_float(rh[it][q] << 16) + __uint_as_float(rl[it][q] << 16);
-                v[2 * q + 1] += __uint_as_float(rh[it][q] & 0xffff0000u) + __uint_as_float(rl[it][q] & 0xffff0000u);
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += __uint_as_float(rh[it][q] << 16) + __uint_as_float(rl[it][q] << 16);
+                    v[2 * q + 1] += __uint_as_float(rh[it][q] & 0xffff0000u) + __uint_as_float(rl[it][q] & 0xffff0000u);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
             uint32_t hi[4], lo[4];
             split8_store_x3(v, hi, lo);
-            u32x4* ys = reinterpret_cast<u32x4*>(p.y + item_ofs(it, nch));
+            u32x4* ys = reinterpret_cast<u32x4*>(p.y + item_ofs(it, nch, ln2));
             const u32x4 vh = {hi[0], hi[1], hi[2], hi[3]}, vl = {lo[0], lo[1], lo[2], lo[3]};
             if (p.nt & 4) { __builtin_nontemporal_store(vh, ys + cq); __builtin_nontemporal_store(vl, ys + 4 + cq); }
             else { ys[cq] = vh; ys[4 + cq] = vl; }
@@ -1462,16 +1517,18 @@ __global__ __launch_bounds__(512) void res2_tail_x3_kernel(Res2TailX3Args p) {
 }
 
 void launch_res2_tail_x3(const void* t1, const void* x, const void* w2, const float* b2, const void* w3, const float* b3, const void* zeros, void* y,
-                         int B, int H, int W, int rev, hipStream_t st) {
+                         int B, int H, int W, int rev, hipStream_t st, const void* p2) {
     Res2TailX3Args a{};
     a.t1 = static_cast<const float*>(t1); a.x = static_cast<const float*>(x); a.w2 = static_cast<const float*>(w2); a.b2 = b2;
     a.w3 = static_cast<const float*>(w3); a.b3 = b3; a.zeros = static_cast<const float*>(zeros); a.y = static_cast<float*>(y);
+    a.p2 = static_cast<const float*>(p2);
     a.B = B; a.H = H; a.W = W; a.rev = rev;
     a.nt = tune_get("NT", 3) | (tune_get("NT_X3", 1) << 2);
     ConvArgs d{};
-    d.B = B; d.H = H; d.W = W; d.Ho = H; d.Wo = W; d.Cin = 64; d.Cout = 256; d.KH = -4; d.KW = -4; d.stride = 1; d.res = x;     // KH = -4: "3x3 + expand" row of the layer report
+    d.B = B; d.H = H; d.W = W; d.Ho = H; d.Wo = W; d.Cin = 64; d.Cout = 256; d.KH = -4; d.KW = -4; d.stride = 1; d.res = p2 ? nullptr : x;     // KH = -4: "3x3 + expand" row of the layer report
     void* tok = prof_begin(d, 4, st);
-    hipLaunchKernelGGL(res2_tail_x3_kernel, dim3(B * (H / 16) * (W / 16)), dim3(512), 0, st, a);
+    if (p2) hipLaunchKernelGGL(res2_tail_x3_kernel<true>, dim3(B * (H / 16) * (W / 16)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(res2_tail_x3_kernel<false>, dim3(B * (H / 16) * (W / 16)), dim3(512), 0, st, a);
     prof_end(tok, st);
 }
 
